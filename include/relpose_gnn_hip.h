@@ -1,0 +1,151 @@
+/*
+ * relpose_gnn_hip.h -- C ABI of the MI355X (gfx950) hot path of relpose-gnn.
+ *
+ * The reference has no FFI of its own: its "plugin API" for this path is the PyTorch
+ * nn.Module contract of PoseNetX_R2 (/root/reference/python/niantic/modules/posenet.py:920-1091)
+ * and all native arithmetic lives in third-party wheels (torchvision / aten conv+BN+ReLU,
+ * torch_geometric MessagePassing.propagate, torch_scatter scatter-mean).  Each entry point below
+ * names the reference interface it replaces.  The host-side mirror of the nn.Module contract
+ * (relpose-gnn_amd/posenet.py) binds these symbols with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to caller-owned, 16-byte aligned memory (except where
+ *     marked HOST); nothing is allocated inside a call; no call synchronises the device
+ *     (except rpg_timing_read);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - tensors are dense fp32, indices are int64 (the dtype of PyG's edge_index);
+ *   - return value: 0 = RPG_OK, negative = error, never throws across the ABI.
+ *   - activations inside the encoder are NHWC ("channels last"): x[n][h][w][c].
+ */
+#ifndef RELPOSE_GNN_HIP_H
+#define RELPOSE_GNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPG_OK 0
+#define RPG_ERR_BAD_ARG (-1)      /* null pointer, non-positive size, unsupported shape/alignment */
+#define RPG_ERR_LAUNCH (-2)       /* hipLaunch / runtime error (hipGetLastError text via rpg_last_error) */
+#define RPG_ERR_WORKSPACE (-3)    /* workspace_bytes smaller than rpg_*_workspace_bytes() */
+
+#define RPG_ABI_VERSION 1
+
+int rpg_abi_version(void);
+/* HOST: static string describing the last RPG_ERR_LAUNCH on this thread ("" if none). */
+const char* rpg_last_error(void);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Encoder primitives (replace aten conv2d + batch_norm + relu + max_pool2d + adaptive_avg_pool */
+/* as reached from torchvision resnet34, call site posenet.py:1037)                              */
+/* ------------------------------------------------------------------------------------------- */
+
+/* data.x.view(N,3,H,-1) (posenet.py:1035, NCHW) -> NHWC with the channel dim padded 3 -> 4 (zero). */
+int rpg_nchw3_to_nhwc4_f32(const float* x_nchw, float* y_nhwc4, int n, int h, int w, void* stream);
+
+/* y = act( conv(x, w) * scale[c] + shift[c] (+ residual) ),  implicit GEMM on f32 MFMA.
+ *   x        [n][h][w][cin]           NHWC, cin % 4 == 0
+ *   w_ohwi   [cout][kh][kw][cin]      (PyTorch OIHW weight permuted once at load time)
+ *   scale/shift [cout]                folded eval-mode BatchNorm: scale = gamma/sqrt(var+eps),
+ *                                     shift = beta - mean*scale; scale may be NULL (=1)
+ *   residual [n][ho][wo][cout] or NULL; relu != 0 applies max(.,0) last
+ *   y        [n][ho][wo][cout],  ho = (h + 2*pad - kh)/stride + 1 (floor), same for wo        */
+int rpg_conv2d_bn_act_nhwc_f32(const float* x, const float* w_ohwi, const float* scale, const float* shift,
+                               const float* residual, float* y, int n, int h, int w, int cin, int cout,
+                               int kh, int kw, int stride, int pad, int relu, void* stream);
+
+/* nn.MaxPool2d(3, stride 2, padding 1), NHWC, c % 4 == 0. */
+int rpg_maxpool3x3s2_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, void* stream);
+
+/* nn.AdaptiveAvgPool2d(1) + flatten: [n][hw][c] -> [n][c]. */
+int rpg_global_avgpool_nhwc_f32(const float* x, float* y, int n, int hw, int c, void* stream);
+
+/* Whole encoder: torchvision-0.9.1 ResNet (BasicBlock) forward incl. the replaced fc
+ * (posenet.py:942-945, :1037).  `tensors` is a HOST array of device pointers laid out as
+ * documented in relpose-gnn_amd/params.py (stem, then per block conv1/conv2/(downsample), each
+ * as {w_ohwi, scale, shift}, then fc weight [feat][512] and bias).  `blocks[4]`/`planes[4]` HOST.
+ * x_nchw [n][3][h][w] -> feat [n][feat_dim].                                                     */
+size_t rpg_resnet_workspace_bytes(int n, int h, int w, const int* planes);
+int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors, const int* blocks, const int* planes,
+                           int feat_dim, const float* x_nchw, int n, int h, int w, float* feat,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------- */
+/* GNN primitives                                                                                */
+/* ------------------------------------------------------------------------------------------- */
+
+/* Index preparation for one edge_index [2][e] (row 0 = source, row 1 = target):
+ *   ends [4][e]    int64: sanitised source, sanitised target, min(s,t), max(s,t)
+ *                  (the last two are compute_edge_features' gather indices, posenet.py:1014-1017)
+ *   rowptr [n+1], perm [e]   CSR of edges grouped by TARGET node, edge ids ascending inside a
+ *                  group (the order torch_scatter's CPU kernel accumulates in)
+ *   cursor [n]     scratch
+ *   status [1]     number of edges with an endpoint outside [0, n) (0 = valid); such edges are
+ *                  left out of the CSR and their endpoints clamped, so no later kernel reads out
+ *                  of bounds.  The host mirror raises IndexError when it is non-zero.
+ * Single workgroup; e and n up to 2^20.                                                          */
+int rpg_graph_prepare(const int64_t* edge_index, int e, int n, int64_t* ends, int32_t* rowptr,
+                      int32_t* cursor, int32_t* perm, int32_t* status, void* stream);
+
+/* compute_edge_features (posenet.py:999-1019): out[e] = [x[min(s,t)], x[max(s,t)]], [e][2d]. */
+int rpg_edge_concat_gather_f32(const float* x, const int64_t* edge_index, int e, int d, float* out, void* stream);
+
+/* out[m][n_out] = act( cat_k( a_k[idx_k[m]] ) @ W^T + bias ) (+ residual): nn.Linear over a row-wise
+ * concatenation of up to three gathered sources that is never materialised
+ * (my_gnn_layer.py:238, :305, :310; posenet.py:1053-1055).  idx_k == NULL means row m itself.
+ *   a_k [rows_k][ld_k] uses its first width_k columns, width_k % 4 == 0, ld_k % 4 == 0
+ *   W   [n_out][sum width_k] (PyTorch Linear layout), bias [n_out] or NULL
+ *   residual [m][n_out] or NULL (added before the activation)                                   */
+int rpg_linear_gather_f32(int n_src, const float* const* a, const int64_t* const* idx, const int* ld,
+                          const int* width, const float* weight, const float* bias, const float* residual,
+                          float* out, int m, int n_out, int relu, void* stream);
+
+/* AttentionBlock core (att.py:20-31) on rows: gtp [r][3c] = [g | theta | phi] projections,
+ * y[r][i] = sum_j softmax_j(phi_i * theta_j) * g_j.                                            */
+int rpg_attention_rows_f32(const float* gtp, int r, int c, float* y, void* stream);
+
+/* torch_scatter.scatter(msg, target, dim=0, dim_size=n, reduce='mean') through the CSR of
+ * rpg_graph_prepare: out[v] = sum_{p in rowptr[v]..rowptr[v+1]} msg[perm[p]] / max(count,1).
+ * msg [e][d], d % 4 == 0.  (my_gnn_layer.py:279,301)                                                        */
+int rpg_scatter_mean_f32(const float* msg, const int32_t* rowptr, const int32_t* perm, int n, int e, int d,
+                         float* out, void* stream);
+
+/* Two 3-output Linear heads on the same rows, concatenated: out[r][0:3] = x W1^T + b1,
+ * out[r][3:6] = x W2^T + b2 (posenet.py:1077-1091).  w6 [6][d] = cat(W1, W2), b6 [6].           */
+int rpg_pose_heads_f32(const float* x, const float* w6, const float* b6, int r, int d, float* out, void* stream);
+
+/* Everything after the encoder for use_gnn=True, use_AP=True, knn<=0 (posenet.py:1052-1091).
+ * `tensors` HOST array of device pointers, order in params.py.
+ * feat [n][d], edge_index [2][e] -> abs_pose [n][6], rel_pose [e][6].
+ * node_out [n][d] / edge_out [e][d]: optional (NULL to skip) copies of the final ReLU'd node and
+ * edge features, i.e. the inputs of the heads; the host mirror uses them to apply the reference's
+ * always-on F.dropout (posenet.py:1073-1075) before calling rpg_pose_heads_f32 itself.
+ * status: device int32, see rpg_graph_prepare.                                                  */
+size_t rpg_gnn_workspace_bytes(int n, int e, int d);
+int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, const float* feat, const int64_t* edge_index,
+                        int n, int e, int d, int gnn_recursion, float* abs_pose, float* rel_pose,
+                        float* node_out, float* edge_out, int32_t* status, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline).  */
+/* ------------------------------------------------------------------------------------------- */
+#define RPG_TIMER_CONV 0          /* implicit-GEMM convolutions                                    */
+#define RPG_TIMER_LINEAR 1        /* gathered Linear GEMMs                                         */
+#define RPG_TIMER_SCATTER 2       /* scatter-mean                                                  */
+#define RPG_TIMER_ATTENTION 3     /* attention rows                                                */
+#define RPG_TIMER_COUNT 4
+/* enable != 0: every launch of the listed kernel classes is bracketed by hipEventRecord. */
+int rpg_timing_enable(int enable);
+/* Synchronises, sums the elapsed time of all bracketed launches since the last read.
+ * HOST outputs, arrays of RPG_TIMER_COUNT: total milliseconds, launches, algorithmic work
+ * (FLOP for CONV/LINEAR/ATTENTION, bytes for SCATTER).                                          */
+int rpg_timing_read(double* ms, long long* launches, double* work);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELPOSE_GNN_HIP_H */

@@ -4,3 +4,13 @@ image-graph GNN -> relative-pose heads, as hand-written HIP kernels behind the r
 from .graph import Batch, Data, fc_batch, fc_edge_index  # noqa: F401
 
 __all__ = ["Batch", "Data", "fc_batch", "fc_edge_index"]
+
+
+def __getattr__(name):          # lazy: importing the package must not require torch.cuda or the built library
+    if name in ("PoseNetX_R2",):
+        from .posenet import PoseNetX_R2
+        return PoseNetX_R2
+    if name in ("resnet34", "ResNet"):
+        from . import resnet
+        return getattr(resnet, name)
+    raise AttributeError(name)

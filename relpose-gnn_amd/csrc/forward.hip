@@ -1,0 +1,254 @@
+// Composite forwards: the whole ResNet (BasicBlock) encoder and the whole GNN + heads, as sequences of the
+// kernels in gemm_f32.hip / encoder_ops.hip / gnn_ops.hip on one stream.  No allocation, no synchronisation:
+// the caller passes a workspace sized by rpg_*_workspace_bytes().
+//
+// Reference control flow restated here:
+//   encoder  torchvision 0.9.1 ResNet._forward_impl with BasicBlock (call site posenet.py:1037)
+//   GNN      /root/reference/python/niantic/modules/posenet.py:1052-1091 and my_gnn_layer.py:293-311
+#include "rpg_common.h"
+
+namespace rpg {
+int launch_relu_inplace(float* x, long n_floats, hipStream_t s);
+}
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
+
+struct Carver {
+    char* base;
+    size_t off;
+    template <class T>
+    T* take(size_t count) {
+        T* p = reinterpret_cast<T*>(base + off);
+        off += align_up(count * sizeof(T), 256);
+        return p;
+    }
+};
+
+// Buffer plan of the encoder (floats): NHWC4 input, stem output, 4 rotating block buffers, pooled vector.
+struct ResnetPlan {
+    int h1, w1, h2, w2;
+    size_t in4, stem, blk, pool, total_bytes;
+};
+
+ResnetPlan plan_resnet(int n, int h, int w, const int* planes) {
+    ResnetPlan p{};
+    p.h1 = conv_out(h, 7, 2, 3); p.w1 = conv_out(w, 7, 2, 3);
+    p.h2 = conv_out(p.h1, 3, 2, 1); p.w2 = conv_out(p.w1, 3, 2, 1);
+    p.in4 = (size_t)n * h * w * 4;
+    p.stem = (size_t)n * p.h1 * p.w1 * planes[0];
+    size_t blk = 0;
+    int hh = p.h2, ww = p.w2;
+    for (int l = 0; l < 4; ++l) {
+        if (l > 0) { hh = conv_out(hh, 3, 2, 1); ww = conv_out(ww, 3, 2, 1); }
+        const size_t sz = (size_t)n * hh * ww * planes[l];
+        if (sz > blk) blk = sz;
+    }
+    p.blk = blk;
+    p.pool = (size_t)n * planes[3];
+    p.total_bytes = align_up(p.in4 * 4, 256) + align_up(p.stem * 4, 256) + 4 * align_up(p.blk * 4, 256) +
+                    align_up(p.pool * 4, 256);
+    return p;
+}
+
+}  // namespace
+
+extern "C" size_t rpg_resnet_workspace_bytes(int n, int h, int w, const int* planes) {
+    if (n <= 0 || h <= 0 || w <= 0 || !planes) return 0;
+    return plan_resnet(n, h, w, planes).total_bytes;
+}
+
+extern "C" int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors, const int* blocks, const int* planes,
+                                      int feat_dim, const float* x_nchw, int n, int h, int w, float* feat,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!tensors || !blocks || !planes || !x_nchw || !feat || !workspace || n <= 0 || h <= 0 || w <= 0 || feat_dim <= 0)
+        return RPG_ERR_BAD_ARG;
+    // tensor count: stem 3 + per block 6 (+3 with downsample) + fc 2
+    int expect = 3 + 2, cin = planes[0];
+    for (int l = 0; l < 4; ++l)
+        for (int b = 0; b < blocks[l]; ++b) {
+            const int stride = (l > 0 && b == 0) ? 2 : 1;
+            expect += 6 + ((stride != 1 || cin != planes[l]) ? 3 : 0);
+            cin = planes[l];
+        }
+    if (n_tensors != expect) return RPG_ERR_BAD_ARG;
+    for (int i = 0; i < n_tensors; ++i)
+        if (!tensors[i]) return RPG_ERR_BAD_ARG;
+    const ResnetPlan p = plan_resnet(n, h, w, planes);
+    if (workspace_bytes < p.total_bytes) return RPG_ERR_WORKSPACE;
+    hipStream_t s = rpg::as_stream(stream);
+
+    Carver cv{reinterpret_cast<char*>(workspace), 0};
+    float* in4 = cv.take<float>(p.in4);
+    float* stem = cv.take<float>(p.stem);
+    float* buf[4];
+    for (int i = 0; i < 4; ++i) buf[i] = cv.take<float>(p.blk);
+    float* pool = cv.take<float>(p.pool);
+
+    int rc;
+    int ti = 0;
+    if ((rc = rpg_nchw3_to_nhwc4_f32(x_nchw, in4, n, h, w, stream)) != RPG_OK) return rc;
+    // stem: conv7x7/2 pad 3 (3 -> planes[0], input channels padded to 4 with zero weights) + BN + ReLU
+    if ((rc = rpg::launch_conv(in4, tensors[ti], tensors[ti + 1], tensors[ti + 2], nullptr, stem, n, h, w, 4,
+                               planes[0], 7, 7, 2, 3, 1, s)) != RPG_OK)
+        return rc;
+    ti += 3;
+    if ((rc = rpg_maxpool3x3s2_nhwc_f32(stem, buf[0], n, p.h1, p.w1, planes[0], stream)) != RPG_OK) return rc;
+
+    int cur = 0, hh = p.h2, ww = p.w2;
+    cin = planes[0];
+    for (int l = 0; l < 4; ++l) {
+        for (int b = 0; b < blocks[l]; ++b) {
+            const int stride = (l > 0 && b == 0) ? 2 : 1;
+            const int c = planes[l];
+            const bool ds = (stride != 1 || cin != c);
+            const int ho = conv_out(hh, 3, stride, 1), wo = conv_out(ww, 3, stride, 1);
+            float* X = buf[cur];
+            float* T = buf[(cur + 1) & 3];
+            float* Y = buf[(cur + 2) & 3];
+            float* D = buf[(cur + 3) & 3];
+            // conv1 3x3/stride + BN + ReLU
+            if ((rc = rpg::launch_conv(X, tensors[ti], tensors[ti + 1], tensors[ti + 2], nullptr, T, n, hh, ww, cin, c, 3,
+                                       3, stride, 1, 1, s)) != RPG_OK)
+                return rc;
+            const float* identity = X;
+            if (ds) {   // downsample: conv1x1/stride + BN (no activation)
+                if ((rc = rpg::launch_conv(X, tensors[ti + 6], tensors[ti + 7], tensors[ti + 8], nullptr, D, n, hh, ww,
+                                           cin, c, 1, 1, stride, 0, 0, s)) != RPG_OK)
+                    return rc;
+                identity = D;
+            }
+            // conv2 3x3/1 + BN + identity + ReLU
+            if ((rc = rpg::launch_conv(T, tensors[ti + 3], tensors[ti + 4], tensors[ti + 5], identity, Y, n, ho, wo, c, c,
+                                       3, 3, 1, 1, 1, s)) != RPG_OK)
+                return rc;
+            ti += ds ? 9 : 6;
+            cur = (cur + 2) & 3;
+            hh = ho; ww = wo; cin = c;
+        }
+    }
+    if ((rc = rpg_global_avgpool_nhwc_f32(buf[cur], pool, n, hh * ww, cin, stream)) != RPG_OK) return rc;
+    rpg::GatherSrc src{};
+    src.n = 1; src.a[0] = pool; src.idx[0] = nullptr; src.ld[0] = cin; src.width[0] = cin;
+    return rpg::launch_linear(src, tensors[ti], tensors[ti + 1], nullptr, feat, n, feat_dim, 0, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// GNN + heads
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+enum GnnTensor {
+    T_PROJ_W, T_PROJ_B, T_EDGE0_W, T_EDGE0_B, T_EDGE2_W, T_EDGE2_B, T_MSG0_W, T_MSG0_B, T_MSG2_W, T_MSG2_B,
+    T_GTP_W, T_GTP_B, T_ATTW_W, T_ATTW_B, T_UPD0_W, T_UPD0_B, T_UPD2_W, T_UPD2_B, T_HEADN_W, T_HEADN_B,
+    T_HEADE_W, T_HEADE_B, T_COUNT
+};
+
+struct GnnPlan {
+    size_t total_bytes;
+};
+size_t gnn_bytes(int n, int e, int d) {
+    const size_t c = d / 8;
+    size_t b = 0;
+    b += align_up((size_t)4 * e * 8, 256);                 // ends
+    b += align_up((size_t)(n + 1) * 4, 256);               // rowptr
+    b += align_up((size_t)n * 4, 256);                     // cursor
+    b += align_up((size_t)e * 4, 256);                     // perm
+    b += 5 * align_up((size_t)e * d * 4, 256);             // e0, e1, hidden, msg, att
+    b += align_up((size_t)e * 3 * c * 4, 256);             // g|theta|phi
+    b += align_up((size_t)e * c * 4, 256);                 // y
+    b += 4 * align_up((size_t)n * d * 4, 256);             // agg, node hidden, x ping-pong
+    return b;
+}
+}  // namespace
+
+extern "C" size_t rpg_gnn_workspace_bytes(int n, int e, int d) {
+    if (n <= 0 || e <= 0 || d <= 0 || (d & 31)) return 0;
+    return gnn_bytes(n, e, d);
+}
+
+extern "C" int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, const float* feat,
+                                   const int64_t* edge_index, int n, int e, int d, int gnn_recursion, float* abs_pose,
+                                   float* rel_pose, float* node_out, float* edge_out, int32_t* status, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    if (!tensors || n_tensors != T_COUNT || !feat || !edge_index || !abs_pose || !rel_pose || !status || !workspace ||
+        n <= 0 || e <= 0 || d <= 0 || (d & 31) || gnn_recursion < 0)
+        return RPG_ERR_BAD_ARG;
+    for (int i = 0; i < T_COUNT; ++i)
+        if (!tensors[i]) return RPG_ERR_BAD_ARG;
+    if (workspace_bytes < gnn_bytes(n, e, d)) return RPG_ERR_WORKSPACE;
+    hipStream_t s = rpg::as_stream(stream);
+    const int c = d / 8;
+
+    Carver cv{reinterpret_cast<char*>(workspace), 0};
+    int64_t* ends = cv.take<int64_t>((size_t)4 * e);
+    int32_t* rowptr = cv.take<int32_t>((size_t)n + 1);
+    int32_t* cursor = cv.take<int32_t>((size_t)n);
+    int32_t* perm = cv.take<int32_t>((size_t)e);
+    float* ebuf[2] = {cv.take<float>((size_t)e * d), cv.take<float>((size_t)e * d)};
+    float* hid = cv.take<float>((size_t)e * d);
+    float* msg = cv.take<float>((size_t)e * d);
+    float* att = cv.take<float>((size_t)e * d);
+    float* gtp = cv.take<float>((size_t)e * 3 * c);
+    float* yat = cv.take<float>((size_t)e * c);
+    float* agg = cv.take<float>((size_t)n * d);
+    float* nhid = cv.take<float>((size_t)n * d);
+    float* xbuf[2] = {cv.take<float>((size_t)n * d), cv.take<float>((size_t)n * d)};
+
+    int rc;
+    if ((rc = rpg_graph_prepare(edge_index, e, n, ends, rowptr, cursor, perm, status, stream)) != RPG_OK) return rc;
+    const int64_t* src = ends;
+    const int64_t* dst = ends + e;
+    const int64_t* lo = ends + 2 * (size_t)e;
+    const int64_t* hi = ends + 3 * (size_t)e;
+
+    auto linear = [&](int ns, const float* a0, const int64_t* i0, int w0, const float* a1, const int64_t* i1, int w1,
+                      const float* a2, const int64_t* i2, int w2, int wt, const float* residual, float* out, int m,
+                      int n_out, int relu) {
+        rpg::GatherSrc g{};
+        g.n = ns;
+        g.a[0] = a0; g.idx[0] = i0; g.ld[0] = w0; g.width[0] = w0;
+        g.a[1] = a1; g.idx[1] = i1; g.ld[1] = w1; g.width[1] = w1;
+        g.a[2] = a2; g.idx[2] = i2; g.ld[2] = w2; g.width[2] = w2;
+        return rpg::launch_linear(g, tensors[wt], tensors[wt + 1], residual, out, m, n_out, relu, s);
+    };
+
+    // edge_feat = relu(proj_edge(cat[x[min], x[max]]))                                   posenet.py:1053-1055
+    const float* x = feat;
+    float* ecur = ebuf[0];
+    if ((rc = linear(2, x, lo, d, x, hi, d, nullptr, nullptr, 0, T_PROJ_W, nullptr, ecur, e, d, 1)) != RPG_OK) return rc;
+
+    for (int r = 0; r < gnn_recursion; ++r) {                                           // posenet.py:1061-1069
+        float* enew = (ecur == ebuf[0]) ? ebuf[1] : ebuf[0];
+        float* xnew = xbuf[r & 1];
+        // edge update: edge_mlp(cat[x[src], x[dst], e])                                 my_gnn_layer.py:296-297
+        if ((rc = linear(3, x, src, d, x, dst, d, ecur, nullptr, d, T_EDGE0_W, nullptr, hid, e, d, 1)) != RPG_OK) return rc;
+        if ((rc = linear(1, hid, nullptr, d, nullptr, nullptr, 0, nullptr, nullptr, 0, T_EDGE2_W, nullptr, enew, e, d, 0)) != RPG_OK) return rc;
+        // message: mlp(cat[x[src], e_new]) then AttentionBlock                          my_gnn_layer.py:304-307
+        if ((rc = linear(2, x, src, d, enew, nullptr, d, nullptr, nullptr, 0, T_MSG0_W, nullptr, hid, e, d, 1)) != RPG_OK) return rc;
+        if ((rc = linear(1, hid, nullptr, d, nullptr, nullptr, 0, nullptr, nullptr, 0, T_MSG2_W, nullptr, msg, e, d, 0)) != RPG_OK) return rc;
+        if ((rc = linear(1, msg, nullptr, d, nullptr, nullptr, 0, nullptr, nullptr, 0, T_GTP_W, nullptr, gtp, e, 3 * c, 0)) != RPG_OK) return rc;
+        if ((rc = rpg_attention_rows_f32(gtp, e, c, yat, stream)) != RPG_OK) return rc;
+        if ((rc = linear(1, yat, nullptr, c, nullptr, nullptr, 0, nullptr, nullptr, 0, T_ATTW_W, msg, att, e, d, 0)) != RPG_OK) return rc;
+        // aggregate (mean over incoming edges) and node update                          my_gnn_layer.py:301,309-311
+        if ((rc = rpg_scatter_mean_f32(att, rowptr, perm, n, e, d, agg, stream)) != RPG_OK) return rc;
+        if ((rc = linear(2, x, nullptr, d, agg, nullptr, d, nullptr, nullptr, 0, T_UPD0_W, nullptr, nhid, n, d, 1)) != RPG_OK) return rc;
+        if ((rc = linear(1, nhid, nullptr, d, nullptr, nullptr, 0, nullptr, nullptr, 0, T_UPD2_W, nullptr, xnew, n, d, 1)) != RPG_OK) return rc;
+        // x = relu(x) is fused above; edge_feat = relu(edge_feat) now that the message has consumed the raw one
+        if ((rc = rpg::launch_relu_inplace(enew, (long)e * d, s)) != RPG_OK) return rc;
+        x = xnew;
+        ecur = enew;
+    }
+    if (node_out && hipMemcpyAsync(node_out, x, (size_t)n * d * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        rpg::set_last_error("gnn_forward node_out", hipGetLastError());
+        return RPG_ERR_LAUNCH;
+    }
+    if (edge_out && hipMemcpyAsync(edge_out, ecur, (size_t)e * d * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        rpg::set_last_error("gnn_forward edge_out", hipGetLastError());
+        return RPG_ERR_LAUNCH;
+    }
+    // heads (droprate == 0, use_AP)                                                     posenet.py:1077-1091
+    if ((rc = rpg_pose_heads_f32(x, tensors[T_HEADN_W], tensors[T_HEADN_B], n, d, abs_pose, stream)) != RPG_OK) return rc;
+    return rpg_pose_heads_f32(ecur, tensors[T_HEADE_W], tensors[T_HEADE_B], e, d, rel_pose, stream);
+}

@@ -1,0 +1,46 @@
+// Shared host-side helpers for the gfx950 kernels of the relpose-gnn hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/relpose_gnn_hip.h"
+
+namespace rpg {
+
+// Last launch error text (thread local), exposed through rpg_last_error().
+void set_last_error(const char* where, hipError_t e);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Kernel timing hooks (timing.hip).  begin() returns a slot (or -1 when timing is disabled).
+int timing_begin(int klass, hipStream_t s);
+void timing_end(int slot, double work, hipStream_t s);
+
+#define RPG_CHECK_LAUNCH(where)                         \
+    do {                                                \
+        hipError_t _e = hipGetLastError();              \
+        if (_e != hipSuccess) {                         \
+            rpg::set_last_error(where, _e);             \
+            return RPG_ERR_LAUNCH;                      \
+        }                                               \
+    } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- internal launchers shared between the fine-grained C ABI and the composite forwards ----
+struct GatherSrc {
+    const float* a[3];
+    const int64_t* idx[3];
+    int ld[3];
+    int width[3];
+    int n;
+};
+
+int launch_conv(const float* x, const float* w, const float* scale, const float* shift, const float* residual,
+                float* y, int n, int h, int wd, int cin, int cout, int kh, int kw, int stride, int pad, int relu,
+                hipStream_t s);
+int launch_linear(const GatherSrc& src, const float* weight, const float* bias, const float* residual, float* out,
+                  int m, int n_out, int relu, hipStream_t s);
+
+}  // namespace rpg

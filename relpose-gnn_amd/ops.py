@@ -1,0 +1,159 @@
+"""Tensor-level wrappers over the C ABI (one Python function per ``rpg_*`` entry point).
+
+PyTorch is used for device memory and the current stream only: every function takes CUDA (ROCm) fp32
+tensors, allocates its output with ``torch.empty`` and launches the HIP kernel on
+``torch.cuda.current_stream()``.  CPU tensors are rejected: there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not torch.is_tensor(t):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the GPU (the HIP kernels are the only compute path), got {t.device}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def nchw3_to_nhwc4(x: torch.Tensor) -> torch.Tensor:
+    x = _req(x, "x")
+    n, c, h, w = x.shape
+    if c != 3:
+        raise ValueError("expected [N,3,H,W]")
+    y = torch.empty((n, h, w, 4), dtype=torch.float32, device=x.device)
+    L.check(L.lib().rpg_nchw3_to_nhwc4_f32(_p(x), _p(y), n, h, w, _stream()), "nchw3_to_nhwc4")
+    return y
+
+
+def conv2d_bn_act_nhwc(x: torch.Tensor, w_ohwi: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor],
+                       residual: Optional[torch.Tensor] = None, stride: int = 1, pad: int = 0, relu: bool = False) -> torch.Tensor:
+    x, w_ohwi = _req(x, "x"), _req(w_ohwi, "w_ohwi")
+    n, h, w, cin = x.shape
+    cout, kh, kw, cin_w = w_ohwi.shape
+    if cin_w != cin:
+        raise ValueError(f"channel mismatch: x has {cin}, weight has {cin_w}")
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+    scale = None if scale is None else _req(scale, "scale")
+    shift = None if shift is None else _req(shift, "shift")
+    residual = None if residual is None else _req(residual, "residual")
+    if residual is not None and residual.shape != y.shape:
+        raise ValueError("residual shape mismatch")
+    L.check(L.lib().rpg_conv2d_bn_act_nhwc_f32(_p(x), _p(w_ohwi), _p(scale), _p(shift), _p(residual), _p(y), n, h, w, cin,
+                                                cout, kh, kw, stride, pad, int(relu), _stream()), "conv2d_bn_act_nhwc")
+    return y
+
+
+def maxpool3x3s2_nhwc(x: torch.Tensor) -> torch.Tensor:
+    x = _req(x, "x")
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
+    L.check(L.lib().rpg_maxpool3x3s2_nhwc_f32(_p(x), _p(y), n, h, w, c, _stream()), "maxpool3x3s2_nhwc")
+    return y
+
+
+def global_avgpool_nhwc(x: torch.Tensor) -> torch.Tensor:
+    x = _req(x, "x")
+    n, h, w, c = x.shape
+    y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    L.check(L.lib().rpg_global_avgpool_nhwc_f32(_p(x), _p(y), n, h * w, c, _stream()), "global_avgpool_nhwc")
+    return y
+
+
+def graph_prepare(edge_index: torch.Tensor, n: int) -> Dict[str, torch.Tensor]:
+    ei = _req(edge_index, "edge_index", torch.int64)
+    if ei.dim() != 2 or ei.shape[0] != 2:
+        raise ValueError("edge_index must be [2, E]")
+    e = ei.shape[1]
+    dev = ei.device
+    ends = torch.empty((4, e), dtype=torch.int64, device=dev)
+    rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    cursor = torch.empty(n, dtype=torch.int32, device=dev)
+    perm = torch.empty(e, dtype=torch.int32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    L.check(L.lib().rpg_graph_prepare(_p(ei), e, n, _p(ends), _p(rowptr), _p(cursor), _p(perm), _p(status), _stream()),
+            "graph_prepare")
+    return {"ends": ends, "rowptr": rowptr, "perm": perm, "status": status}
+
+
+def edge_concat_gather(x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+    x, ei = _req(x, "x"), _req(edge_index, "edge_index", torch.int64)
+    e, d = ei.shape[1], x.shape[1]
+    out = torch.empty((e, 2 * d), dtype=torch.float32, device=x.device)
+    L.check(L.lib().rpg_edge_concat_gather_f32(_p(x), _p(ei), e, d, _p(out), _stream()), "edge_concat_gather")
+    return out
+
+
+def linear_gather(sources: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]], weight: torch.Tensor,
+                  bias: Optional[torch.Tensor], m: int, residual: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    """out[m] = act(cat_k(a_k[idx_k[m]]) @ weight.T + bias (+ residual)); sources = [(a_k, idx_k or None), ...]."""
+    ns = len(sources)
+    keep = [(_req(a, f"a{i}"), None if ix is None else _req(ix, f"idx{i}", torch.int64)) for i, (a, ix) in enumerate(sources)]
+    weight = _req(weight, "weight")
+    bias = None if bias is None else _req(bias, "bias")
+    residual = None if residual is None else _req(residual, "residual")
+    n_out = weight.shape[0]
+    if sum(a.shape[1] for a, _ in keep) != weight.shape[1]:
+        raise ValueError("sum of source widths != weight.shape[1]")
+    out = torch.empty((m, n_out), dtype=torch.float32, device=weight.device)
+    a_arr = L.ptr_array([a.data_ptr() for a, _ in keep])
+    i_arr = L.ptr_array([None if ix is None else ix.data_ptr() for _, ix in keep])
+    ld = L.int_array([a.shape[1] for a, _ in keep])
+    wd = L.int_array([a.shape[1] for a, _ in keep])
+    L.check(L.lib().rpg_linear_gather_f32(ns, a_arr, i_arr, ld, wd, _p(weight), _p(bias), _p(residual), _p(out), m, n_out,
+                                           int(relu), _stream()), "linear_gather")
+    return out
+
+
+def attention_rows(gtp: torch.Tensor) -> torch.Tensor:
+    gtp = _req(gtp, "gtp")
+    r, c3 = gtp.shape
+    c = c3 // 3
+    y = torch.empty((r, c), dtype=torch.float32, device=gtp.device)
+    L.check(L.lib().rpg_attention_rows_f32(_p(gtp), r, c, _p(y), _stream()), "attention_rows")
+    return y
+
+
+def scatter_mean(msg: torch.Tensor, rowptr: torch.Tensor, perm: torch.Tensor, n: int) -> torch.Tensor:
+    msg = _req(msg, "msg")
+    rowptr, perm = _req(rowptr, "rowptr", torch.int32), _req(perm, "perm", torch.int32)
+    e, d = msg.shape
+    out = torch.empty((n, d), dtype=torch.float32, device=msg.device)
+    L.check(L.lib().rpg_scatter_mean_f32(_p(msg), _p(rowptr), _p(perm), n, e, d, _p(out), _stream()), "scatter_mean")
+    return out
+
+
+def pose_heads(x: torch.Tensor, w6: torch.Tensor, b6: torch.Tensor) -> torch.Tensor:
+    x, w6, b6 = _req(x, "x"), _req(w6, "w6"), _req(b6, "b6")
+    r, d = x.shape
+    out = torch.empty((r, 6), dtype=torch.float32, device=x.device)
+    L.check(L.lib().rpg_pose_heads_f32(_p(x), _p(w6), _p(b6), r, d, _p(out), _stream()), "pose_heads")
+    return out
+
+
+def timing_enable(on: bool) -> None:
+    L.check(L.lib().rpg_timing_enable(int(on)), "timing_enable")
+
+
+def timing_read() -> Dict[str, Dict[str, float]]:
+    n = len(L.TIMER_NAMES)
+    ms, cnt, work = (C.c_double * n)(), (C.c_longlong * n)(), (C.c_double * n)()
+    L.check(L.lib().rpg_timing_read(ms, cnt, work), "timing_read")
+    return {name: {"ms": ms[i], "launches": int(cnt[i]), "work": work[i]} for i, name in enumerate(L.TIMER_NAMES)}

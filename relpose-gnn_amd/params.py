@@ -1,0 +1,108 @@
+"""Packing of a PoseNetX_R2 state dict into the device tensors the C ABI consumes.
+
+Done once per weight load (``PoseNetX_R2._packed()``), on the model's device, with torch used only to
+permute / concatenate / fold constants:
+
+encoder (``rpg_resnet_forward_f32`` tensor order)
+    for the stem, then every BasicBlock's conv1, conv2 and (if present) downsample conv:
+        w_ohwi  [Cout][KH][KW][Cin]   = PyTorch OIHW weight permuted to channels-last; the stem's 3 input
+                                        channels are zero-padded to 4 so every im2col chunk is one 16-byte load
+        scale   [Cout] = gamma / sqrt(running_var + eps)          (eval-mode BatchNorm folded to an affine
+        shift   [Cout] = beta - running_mean * scale               epilogue; the conv weights are untouched)
+    then fc.weight [feat][512], fc.bias [feat]
+
+GNN (``rpg_gnn_forward_f32`` tensor order, 22 tensors)
+    proj_edge.{weight,bias}; gnn1.edge_model.edge_mlp.{0,2}.{weight,bias}; gnn1.mlp.{0,2}.{weight,bias};
+    att g|theta|phi weights concatenated to [3C][D] and biases to [3C]; gnn1.att.W.{weight,bias};
+    gnn1.mlp_updating.{0,2}.{weight,bias}; node heads cat(fc_xyz, fc_wpqr) -> [6][D],[6];
+    edge heads cat(fc_xyz_R, fc_wpqr_R) -> [6][D],[6].
+Linear weights keep the PyTorch [out][in] layout (both GEMM operands are K-contiguous).
+
+Reference: /root/reference/python/niantic/modules/posenet.py:941-975 (module inventory),
+my_gnn_layer.py:280-291, att.py:9-14; BatchNorm eps = 1e-5 (torch default used by torchvision).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+
+BN_EPS = 1e-5
+
+
+def _bn_affine(sd: Dict[str, torch.Tensor], p: str, eps: float = BN_EPS) -> Tuple[torch.Tensor, torch.Tensor]:
+    scale = sd[p + "weight"].float() / torch.sqrt(sd[p + "running_var"].float() + eps)
+    shift = sd[p + "bias"].float() - sd[p + "running_mean"].float() * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def _ohwi(w: torch.Tensor, pad_cin_to: int = 0) -> torch.Tensor:
+    w = w.float().permute(0, 2, 3, 1)
+    if pad_cin_to and w.shape[-1] < pad_cin_to:
+        w = torch.nn.functional.pad(w, (0, pad_cin_to - w.shape[-1]))
+    return w.contiguous()
+
+
+def resnet_structure(sd: Dict[str, torch.Tensor], prefix: str) -> Tuple[List[int], List[int]]:
+    """(blocks per layer, planes per layer) read off the state-dict keys."""
+    blocks, planes = [], []
+    for li in range(1, 5):
+        b = 0
+        while f"{prefix}layer{li}.{b}.conv1.weight" in sd:
+            b += 1
+        if b == 0:
+            raise KeyError(f"{prefix}layer{li}.0.conv1.weight missing: not a torchvision-style ResNet state dict")
+        blocks.append(b)
+        planes.append(int(sd[f"{prefix}layer{li}.0.conv1.weight"].shape[0]))
+    return blocks, planes
+
+
+def pack_resnet(sd: Dict[str, torch.Tensor], prefix: str = "feature_extractor.") -> Tuple[List[torch.Tensor], List[int], List[int]]:
+    blocks, planes = resnet_structure(sd, prefix)
+    t: List[torch.Tensor] = []
+    w = sd[prefix + "conv1.weight"]
+    if tuple(w.shape[1:]) != (3, 7, 7) or w.shape[0] != planes[0]:
+        raise ValueError("stem must be Conv2d(3, planes[0], 7, stride 2, pad 3)")
+    t += [_ohwi(w, pad_cin_to=4), *_bn_affine(sd, prefix + "bn1.")]
+    cin = planes[0]
+    for li, (nb, c) in enumerate(zip(blocks, planes), start=1):
+        for b in range(nb):
+            p = f"{prefix}layer{li}.{b}."
+            stride = 2 if (li > 1 and b == 0) else 1
+            if tuple(sd[p + "conv1.weight"].shape) != (c, cin, 3, 3) or tuple(sd[p + "conv2.weight"].shape) != (c, c, 3, 3):
+                raise ValueError(f"{p}: not a BasicBlock with 3x3 convolutions")
+            t += [_ohwi(sd[p + "conv1.weight"]), *_bn_affine(sd, p + "bn1.")]
+            t += [_ohwi(sd[p + "conv2.weight"]), *_bn_affine(sd, p + "bn2.")]
+            has_ds = (p + "downsample.0.weight") in sd
+            if has_ds != (stride != 1 or cin != c):
+                raise ValueError(f"{p}: downsample presence does not match the torchvision BasicBlock rule")
+            if has_ds:
+                t += [_ohwi(sd[p + "downsample.0.weight"]), *_bn_affine(sd, p + "downsample.1.")]
+            cin = c
+    t += [sd[prefix + "fc.weight"].float().contiguous(), sd[prefix + "fc.bias"].float().contiguous()]
+    return t, blocks, planes
+
+
+GNN_TENSOR_ORDER = (
+    "proj_edge", "edge_mlp.0", "edge_mlp.2", "mlp.0", "mlp.2", "att.gtp", "att.W", "mlp_updating.0", "mlp_updating.2",
+    "heads.node", "heads.edge")
+
+
+def pack_gnn(sd: Dict[str, torch.Tensor], gnn: str = "gnn1.") -> List[torch.Tensor]:
+    def lin(name):
+        return [sd[name + ".weight"].float().contiguous(), sd[name + ".bias"].float().contiguous()]
+
+    def cat(names):
+        return [torch.cat([sd[n + ".weight"].float() for n in names], 0).contiguous(),
+                torch.cat([sd[n + ".bias"].float() for n in names], 0).contiguous()]
+
+    t: List[torch.Tensor] = []
+    t += lin("proj_edge")
+    t += lin(gnn + "edge_model.edge_mlp.0") + lin(gnn + "edge_model.edge_mlp.2")
+    t += lin(gnn + "mlp.0") + lin(gnn + "mlp.2")
+    t += cat([gnn + "att.g", gnn + "att.theta", gnn + "att.phi"])
+    t += lin(gnn + "att.W")
+    t += lin(gnn + "mlp_updating.0") + lin(gnn + "mlp_updating.2")
+    t += cat(["fc_xyz", "fc_wpqr"])
+    t += cat(["fc_xyz_R", "fc_wpqr_R"])
+    return t

@@ -1,0 +1,186 @@
+"""``PoseNetX_R2``: host-side mirror of the reference model's nn.Module contract over the HIP hot path.
+
+Same constructor keywords, ``forward(data, k=None) -> (abs_pose[N,6], rel_pose[E,6], edge_index[2,E])`` signature,
+``data.x / data.edge_index`` input contract and state-dict key names as
+/root/reference/python/niantic/modules/posenet.py:920-1091, so it drops into the evaluation scripts
+(testing/test.py:157-167,211) and loads their checkpoints.  The sub-modules below (``nn.Linear`` holders named like the
+reference's ``simpleConvEdge_upt`` / ``simpleEdgeModel`` / ``AttentionBlock`` children, my_gnn_layer.py:280-291,
+att.py:9-14) only own parameters; the arithmetic is two C calls, ``rpg_resnet_forward_f32`` and ``rpg_gnn_forward_f32``.
+
+Supported configuration = the hot path: ``use_gnn=True, use_AP=True, use_attention=False, knn<=0, k=None``.
+The reference's always-on dropout (``F.dropout`` without ``training=``, posenet.py:1073-1075) is honoured: with
+``droprate>0`` the node/edge features come back from the GNN call, ``F.dropout`` is applied, and the heads kernel runs on
+the result; parity tests use ``droprate=0``.  Everything runs on the GPU; CPU tensors raise (no fallback).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as _L
+from . import ops
+from .params import pack_gnn
+from .resnet import EncoderRunner
+
+
+class AttentionBlock(nn.Module):
+    """Parameter holder with the reference's child names (att.py:9-14)."""
+
+    def __init__(self, in_channels: int):
+        super().__init__()
+        self.g = nn.Linear(in_channels, in_channels // 8)
+        self.theta = nn.Linear(in_channels, in_channels // 8)
+        self.phi = nn.Linear(in_channels, in_channels // 8)
+        self.W = nn.Linear(in_channels // 8, in_channels)
+
+
+class simpleEdgeModel(nn.Module):  # noqa: N801 - reference spelling (my_gnn_layer.py:224)
+    def __init__(self, in_channels: int, edge_channels: int, out_channels: int):
+        super().__init__()
+        self.edge_mlp = nn.Sequential(nn.Linear(2 * in_channels + edge_channels, out_channels), nn.ReLU(),
+                                      nn.Linear(out_channels, out_channels))
+
+
+class simpleConvEdge_upt(nn.Module):  # noqa: N801 - reference spelling (my_gnn_layer.py:277)
+    def __init__(self, in_channels: int, edge_channels: int, out_channels: int):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(in_channels + edge_channels, out_channels), nn.ReLU(),
+                                 nn.Linear(out_channels, out_channels))
+        self.mlp_updating = nn.Sequential(nn.Linear(2 * in_channels, out_channels), nn.ReLU(),
+                                          nn.Linear(out_channels, out_channels))
+        self.edge_model = simpleEdgeModel(in_channels, edge_channels, edge_channels)
+        self.att = AttentionBlock(in_channels)
+
+
+class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
+    def __init__(self, feature_extractor, droprate=0.5, pretrained=True,
+                 feat_dim=1024, edge_feat_dim=1024, node_dim=1024,
+                 filter_nans=False, input_img_height=256, use_gnn=False, use_attention=False,
+                 knn=-1, use_AP=True, gnn_recursion=2, device: int = 0, L: int = 1):
+        super().__init__()
+        if not use_gnn:
+            raise NotImplementedError("use_gnn=False is outside the accelerated path (and unreachable in the reference: "
+                                      "posenet.py:987-989 touches an undefined self.mlp)")
+        if use_attention or not use_AP or L != 1:
+            raise NotImplementedError("only use_attention=False, use_AP=True, L=1 (the R3 evaluation configuration, "
+                                      "testing/test.py:161-167) is built so far")
+        if not (feat_dim == node_dim == edge_feat_dim) or feat_dim % 32:
+            raise NotImplementedError("feat_dim == node_dim == edge_feat_dim, a multiple of 32, is required")
+        self.droprate = droprate
+        self.input_img_height = input_img_height
+        self.use_gnn, self.n_layers, self.use_attention = use_gnn, L, use_attention
+        self.knn, self.use_AP, self.gnn_recursion, self.device = knn, use_AP, gnn_recursion, device
+
+        # replace the encoder's pooling and last FC exactly as the reference does (posenet.py:942-945)
+        self.feature_extractor = feature_extractor
+        self.feature_extractor.avgpool = nn.AdaptiveAvgPool2d(1)
+        fe_out_planes = self.feature_extractor.fc.in_features
+        self.feature_extractor.fc = nn.Linear(fe_out_planes, feat_dim)
+        self.proj_edge = nn.Linear(feat_dim * 2, edge_feat_dim)
+        self.gnn1 = simpleConvEdge_upt(node_dim, edge_feat_dim, node_dim)
+        self.fc_xyz = nn.Linear(node_dim, 3)
+        self.fc_wpqr = nn.Linear(node_dim, 3)
+        self.fc_xyz_R = nn.Linear(node_dim, 3)
+        self.fc_wpqr_R = nn.Linear(node_dim, 3)
+
+        # initialisation rule of posenet.py:981-997
+        if pretrained:
+            init_modules = [self.feature_extractor.fc, self.proj_edge, self.fc_xyz, self.fc_wpqr, self.fc_xyz_R,
+                            self.fc_wpqr_R, self.gnn1]
+        else:
+            init_modules = self.modules()
+        for m in init_modules:
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.kaiming_normal_(m.weight.data)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias.data, 0)
+
+        self._enc = EncoderRunner()
+        self._gnn_packed: Optional[List[torch.Tensor]] = None
+        self._gnn_ptrs = None
+        self._gnn_ws: Dict[Tuple, torch.Tensor] = {}
+        self._checked_edges: Dict[Tuple, bool] = {}
+
+    # ---- packed-weight cache ------------------------------------------------------------------------------------
+    def refresh_packed(self) -> None:
+        """Drop the packed device copies of the weights (call after mutating parameters in place)."""
+        self._enc.invalidate()
+        self._gnn_packed, self._gnn_ptrs = None, None
+        self._gnn_ws.clear()
+        self._checked_edges.clear()
+
+    def _apply(self, fn, *a, **k):
+        if hasattr(self, "_enc"):
+            self.refresh_packed()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.refresh_packed()
+        return super().load_state_dict(*a, **k)
+
+    # ---- reference API ------------------------------------------------------------------------------------------
+    def compute_RP(self, p, edge_index):
+        """Relative pose targets p[src] - p[dst] (posenet.py:1021-1031; training-side helper, plain indexing)."""
+        return p[edge_index[0]] - p[edge_index[1]]
+
+    @torch.no_grad()
+    def forward(self, data, k=None):
+        if k is not None or self.knn > 0:
+            raise NotImplementedError("kNN graphs (posenet.py:1043-1050) are a later row of the scope table; "
+                                      "construct with knn=-1 and call forward(data) for the fully-connected path")
+        x, edge_index = data.x, data.edge_index
+        if not x.is_cuda:
+            raise RuntimeError("PoseNetX_R2 (HIP) needs its inputs on the GPU: call data.to(device) first "
+                               "(there is no CPU fallback)")
+        lib = _L.lib()
+        x = x.view(x.size(0), 3, self.input_img_height, -1)                       # posenet.py:1035
+        feat = self._enc.run(self.feature_extractor.state_dict, "", x)            # posenet.py:1037
+
+        if self._gnn_packed is None:
+            sd = {kk: v.detach() for kk, v in self.state_dict().items() if not kk.startswith("feature_extractor.")}
+            self._gnn_packed = pack_gnn(sd)
+            self._gnn_ptrs = _L.ptr_array([t.data_ptr() for t in self._gnn_packed])
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError("edge_index must be an int64 tensor of shape [2, E]")
+        ei = edge_index.contiguous()
+        n, d = feat.shape
+        e = ei.size(1)
+        dev = feat.device
+        key = (n, e, d, dev)
+        ws = self._gnn_ws.get(key)
+        if ws is None:
+            ws = torch.empty(lib.rpg_gnn_workspace_bytes(n, e, d), dtype=torch.uint8, device=dev)
+            self._gnn_ws = {key: ws}
+        abs_pose = torch.empty((n, 6), dtype=torch.float32, device=dev)
+        rel_pose = torch.empty((e, 6), dtype=torch.float32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        drop = self.droprate > 0
+        node_f = torch.empty((n, d), dtype=torch.float32, device=dev) if drop else None
+        edge_f = torch.empty((e, d), dtype=torch.float32, device=dev) if drop else None
+        rc = lib.rpg_gnn_forward_f32(self._gnn_ptrs, len(self._gnn_packed), feat.data_ptr(), ei.data_ptr(), n, e, d,
+                                     int(self.gnn_recursion), abs_pose.data_ptr(), rel_pose.data_ptr(),
+                                     None if node_f is None else node_f.data_ptr(),
+                                     None if edge_f is None else edge_f.data_ptr(), status.data_ptr(), ws.data_ptr(),
+                                     ws.numel(), torch.cuda.current_stream().cuda_stream)
+        _L.check(rc, "gnn_forward")
+
+        # index validation: the reference would raise from aten indexing; check once per edge_index tensor
+        ekey = (ei.data_ptr(), e, n, ei._version)
+        if ekey not in self._checked_edges:
+            bad = int(status.item())
+            if bad:
+                raise IndexError(f"edge_index has {bad} edge(s) with a node id outside [0, {n})")
+            if len(self._checked_edges) > 64:
+                self._checked_edges.clear()
+            self._checked_edges[ekey] = True
+
+        if drop:                                                                  # posenet.py:1073-1075 (always on)
+            node_f = F.dropout(node_f, p=self.droprate)
+            edge_f = F.dropout(edge_f, p=self.droprate)
+            t = self._gnn_packed
+            abs_pose = ops.pose_heads(node_f, t[18], t[19])
+            rel_pose = ops.pose_heads(edge_f, t[20], t[21])
+        return abs_pose, rel_pose, edge_index

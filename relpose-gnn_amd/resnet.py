@@ -1,0 +1,130 @@
+"""torchvision-shaped ResNet (BasicBlock) parameter container whose forward runs the HIP encoder.
+
+torchvision is not a dependency.  The reference builds its encoder with ``torchvision.models.resnet34``
+(/root/reference/python/niantic/testing/test.py:151) and hands it to ``PoseNetX_R2`` which replaces ``.avgpool`` and
+``.fc`` (/root/reference/python/niantic/modules/posenet.py:942-945).  ``resnet34()`` here returns a module with the same
+attribute names and state-dict keys (conv1, bn1, layer{1..4}.{i}.{conv1,bn1,conv2,bn2,downsample.{0,1}}, fc), so
+checkpoints load unchanged.  The sub-modules are ordinary ``nn.Conv2d`` / ``nn.BatchNorm2d`` / ``nn.Linear`` objects used
+as parameter holders only: the arithmetic is ``rpg_resnet_forward_f32`` (implicit-GEMM MFMA convolutions with the
+BatchNorm / residual / ReLU epilogue fused, NHWC activations).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .params import pack_resnet
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1 or inplanes != planes:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        self.stride = stride
+
+    def forward(self, x):  # pragma: no cover - never used: the whole encoder is one C call
+        raise RuntimeError("BasicBlock is a parameter container; call the enclosing ResNet / PoseNetX_R2")
+
+
+class EncoderRunner:
+    """Packs an encoder state dict for the C ABI and runs it; shared by ``ResNet.forward`` and ``PoseNetX_R2``."""
+
+    def __init__(self):
+        self._packed: Optional[Tuple[List[torch.Tensor], List[int], List[int]]] = None
+        self._ptrs = None
+        self._ws: Dict[Tuple, torch.Tensor] = {}
+
+    def invalidate(self) -> None:
+        self._packed, self._ptrs = None, None
+        self._ws.clear()
+
+    def run(self, state_dict_fn, prefix: str, x_nchw: torch.Tensor) -> torch.Tensor:
+        if not x_nchw.is_cuda:
+            raise RuntimeError("the encoder runs on the GPU only (HIP kernels, no CPU fallback); got " + str(x_nchw.device))
+        if x_nchw.dtype != torch.float32 or x_nchw.dim() != 4 or x_nchw.shape[1] != 3:
+            raise ValueError("expected fp32 [N,3,H,W]")
+        lib = L.lib()
+        if self._packed is None:
+            with torch.no_grad():
+                sd = {k: v.detach() for k, v in state_dict_fn().items()}
+                self._packed = pack_resnet(sd, prefix)
+            if any(t.device != x_nchw.device for t in self._packed[0]):
+                self._packed = None
+                raise RuntimeError("encoder weights and input are on different devices")
+            self._ptrs = L.ptr_array([t.data_ptr() for t in self._packed[0]])
+        tensors, blocks, planes = self._packed
+        x = x_nchw.contiguous()
+        n, _, h, w = x.shape
+        feat_dim = tensors[-2].shape[0]
+        planes_c = L.int_array(planes)
+        key = (n, h, w, x.device)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = lib.rpg_resnet_workspace_bytes(n, h, w, planes_c)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            self._ws = {key: ws}          # keep one shape's workspace alive
+        feat = torch.empty((n, feat_dim), dtype=torch.float32, device=x.device)
+        rc = lib.rpg_resnet_forward_f32(self._ptrs, len(tensors), L.int_array(blocks), planes_c, feat_dim, x.data_ptr(),
+                                        n, h, w, feat.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        torch.cuda.current_stream().cuda_stream)
+        L.check(rc, "resnet_forward")
+        return feat
+
+
+class ResNet(nn.Module):
+    def __init__(self, layers: Sequence[int] = (3, 4, 6, 3), planes: Sequence[int] = (64, 128, 256, 512), num_classes: int = 1000):
+        super().__init__()
+        self.inplanes = planes[0]
+        self.conv1 = nn.Conv2d(3, planes[0], 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes[0])
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        for li, (c, nb) in enumerate(zip(planes, layers), start=1):
+            blocks = []
+            for b in range(nb):
+                blocks.append(BasicBlock(self.inplanes, c, 2 if (li > 1 and b == 0) else 1))
+                self.inplanes = c
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(planes[-1], num_classes)
+        self._runner = EncoderRunner()
+
+    def _apply(self, fn, *a, **k):
+        self._runner.invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._runner.invalidate()
+        return super().load_state_dict(*a, **k)
+
+    def refresh_packed(self) -> None:
+        """Call after mutating parameters in place (the packed device copies are cached)."""
+        self._runner.invalidate()
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x [N,3,H,W] -> [N, fc.out_features]; global average pooling regardless of ``self.avgpool``'s output size 1."""
+        return self._runner.run(self.state_dict, "", x)
+
+
+def resnet34(pretrained: bool = False, **kw) -> ResNet:
+    """Same call shape as ``torchvision.models.resnet34``.  ``pretrained=True`` cannot download ImageNet weights here
+    (no network); load a checkpoint with ``load_state_dict`` instead."""
+    if pretrained:
+        import warnings
+        warnings.warn("resnet34(pretrained=True): no network access, weights stay randomly initialised; "
+                      "load a state dict explicitly")
+    return ResNet((3, 4, 6, 3), (64, 128, 256, 512), **kw)

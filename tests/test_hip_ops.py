@@ -1,0 +1,221 @@
+"""GPU parity tests, one per C-ABI entry point: HIP kernel vs a plain PyTorch-CPU fp32 statement of the same op
+(the pieces of oracle/posenet_ref.py).  Tolerance 1e-5 relative (max-norm) per op -- an order below the 1e-4 the
+north-star allows for the whole forward; index work (graph_prepare, edge gather, max-pool) is bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def test_nchw_to_nhwc4(dev):
+    from relpose_gnn_amd import ops
+    x = _rand(3, 3, 17, 23)
+    y = ops.nchw3_to_nhwc4(x.to(dev)).cpu()
+    ref = F.pad(x.permute(0, 2, 3, 1), (0, 1))
+    assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,k,stride,pad,res,relu", [
+    (2, 9, 11, 8, 16, 3, 1, 1, False, True),       # ragged M (198 rows), tiny channels, 64x64 tile
+    (1, 16, 16, 4, 64, 7, 2, 3, False, True),      # stem shape: Cin padded to 4, K=196 (tail masked)
+    (2, 14, 14, 64, 128, 3, 2, 1, False, True),    # strided 3x3
+    (2, 14, 14, 64, 128, 1, 2, 0, False, False),   # downsample 1x1/2, no activation
+    (2, 28, 28, 128, 128, 3, 1, 1, True, True),    # residual + relu
+    (40, 56, 56, 64, 64, 3, 1, 1, True, True),     # layer1 shape, M=125440 -> 256x64 tile path (N<=64, M>=65536)
+    (16, 28, 28, 128, 256, 3, 1, 1, False, True),  # M=12544, N=256 -> tiles: 98*2=196 <384 -> 64x64
+    (64, 28, 28, 128, 128, 3, 1, 1, True, True),   # M=50176, N=128 -> 392 tiles of 128x128
+])
+def test_conv_bn_act(dev, n, h, w, cin, cout, k, stride, pad, res, relu):
+    from relpose_gnn_amd import ops
+    x = _rand(n, cin, h, w, seed=1)
+    wt = _rand(cout, cin, k, k, seed=2, scale=(2.0 / (cin * k * k)) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(3)) + 0.5
+    shift = _rand(cout, seed=4, scale=0.1)
+    ref = F.conv2d(x, wt, None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    r = None
+    if res:
+        r = _rand(*ref.shape, seed=5)
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    y = ops.conv2d_bn_act_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev),
+                               scale.to(dev), shift.to(dev), None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev),
+                               stride=stride, pad=pad, relu=relu)
+    assert y.shape == (n, ref.shape[2], ref.shape[3], cout)
+    err = rel_err(y.cpu().permute(0, 3, 1, 2), ref)
+    assert err < TOL, err
+
+
+def test_conv_transpose_detecting(dev):
+    """A = identity-like input, asymmetric weights: catches a row/col swap in the MFMA C layout."""
+    from relpose_gnn_amd import ops
+    cin, cout = 64, 128
+    x = torch.zeros(1, cin, 8, 8)
+    for c in range(cin):
+        x[0, c, c % 8, c // 8] = 1.0 + c
+    wt = torch.arange(cout * cin, dtype=torch.float32).view(cout, cin, 1, 1) * 1e-3
+    ref = F.conv2d(x, wt)
+    y = ops.conv2d_bn_act_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev), None, None)
+    assert rel_err(y.cpu().permute(0, 3, 1, 2), ref) < 1e-6
+
+
+def test_maxpool_and_avgpool(dev):
+    from relpose_gnn_amd import ops
+    x = _rand(3, 16, 13, 18, seed=7)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    assert torch.equal(ops.maxpool3x3s2_nhwc(xn).cpu().permute(0, 3, 1, 2), F.max_pool2d(x, 3, 2, 1))
+    assert rel_err(ops.global_avgpool_nhwc(xn).cpu(), x.mean(dim=(2, 3))) < 1e-6
+
+
+def _fc_edges(n, b):
+    from relpose_gnn_amd.graph import fc_edge_index
+    ei = fc_edge_index(n)
+    return torch.cat([ei + g * n for g in range(b)], 1)
+
+
+@pytest.mark.parametrize("n_nodes,b", [(8, 1), (8, 5), (4, 3), (8, 300)])
+def test_graph_prepare_fc(dev, n_nodes, b):
+    from relpose_gnn_amd import ops
+    ei = _fc_edges(n_nodes, b)
+    n = n_nodes * b
+    g = ops.graph_prepare(ei.to(dev), n)
+    assert int(g["status"].item()) == 0
+    ends = g["ends"].cpu()
+    assert torch.equal(ends[0], ei[0]) and torch.equal(ends[1], ei[1])
+    assert torch.equal(ends[2], torch.minimum(ei[0], ei[1])) and torch.equal(ends[3], torch.maximum(ei[0], ei[1]))
+    rowptr, perm = g["rowptr"].cpu().long(), g["perm"].cpu().long()
+    order = torch.sort(ei[1], stable=True).indices          # edges grouped by target, ascending edge id inside
+    assert torch.equal(perm, order)
+    assert torch.equal(rowptr, torch.cat([torch.zeros(1, dtype=torch.long), torch.bincount(ei[1], minlength=n).cumsum(0)]))
+
+
+def test_graph_prepare_ragged_and_invalid(dev):
+    from relpose_gnn_amd import ops
+    g0 = torch.Generator().manual_seed(11)
+    n, e = 37, 501
+    ei = torch.randint(0, n, (2, e), generator=g0)
+    ei[1, :40] = 5                                  # a hub node and several isolated ones
+    g = ops.graph_prepare(ei.to(dev), n)
+    assert int(g["status"].item()) == 0
+    assert torch.equal(g["perm"].cpu().long(), torch.sort(ei[1], stable=True).indices)
+    bad = ei.clone()
+    bad[0, 3], bad[1, 9] = n, -1
+    g = ops.graph_prepare(bad.to(dev), n)
+    assert int(g["status"].item()) == 2
+    assert int(g["rowptr"].cpu()[-1]) == e - 2      # the two bad edges are not in the CSR
+    assert int(g["ends"].max()) < n and int(g["ends"].min()) >= 0
+
+
+def test_edge_concat_gather(dev):
+    from relpose_gnn_amd import ops
+    from oracle.posenet_ref import edge_concat
+    x = _rand(24, 64, seed=3)
+    ei = _fc_edges(8, 3)
+    assert torch.equal(ops.edge_concat_gather(x.to(dev), ei.to(dev)).cpu(), edge_concat(x, ei))
+
+
+@pytest.mark.parametrize("m,widths,n_out,gather,res,relu", [
+    (56, (64, 64, 64), 64, True, False, True),        # edge_mlp.0 at D=64
+    (8, (64,), 192, False, False, False),             # att g|theta|phi at D=64
+    (56, (8,), 64, False, True, False),               # att.W: K=8 (< BK), residual
+    (1792, (256, 256), 256, True, False, True),       # ragged-free mid size
+    (300, (128, 64), 96, True, False, False),         # N not a multiple of 64, M ragged
+    (2048, (512,), 2048, False, False, False),        # 128x128 tile path (16*16=256 tiles <384 -> 64x64) large K
+    (6272, (512, 512, 512), 1024, True, True, True),  # 49*8=392 tiles -> 128x128 path, three gathered sources
+])
+def test_linear_gather(dev, m, widths, n_out, gather, res, relu):
+    from relpose_gnn_amd import ops
+    g0 = torch.Generator().manual_seed(5)
+    rows = 97
+    srcs, cpu_cat = [], []
+    for i, wd in enumerate(widths):
+        if gather:
+            a = _rand(rows, wd, seed=10 + i)
+            idx = torch.randint(0, rows, (m,), generator=g0)
+            srcs.append((a.to(dev), idx.to(dev)))
+            cpu_cat.append(a[idx])
+        else:
+            a = _rand(m, wd, seed=10 + i)
+            srcs.append((a.to(dev), None))
+            cpu_cat.append(a)
+    k = sum(widths)
+    wt = _rand(n_out, k, seed=20, scale=k ** -0.5)
+    bias = _rand(n_out, seed=21, scale=0.1)
+    ref = F.linear(torch.cat(cpu_cat, 1), wt, bias)
+    r = None
+    if res:
+        r = _rand(m, n_out, seed=22)
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    y = ops.linear_gather(srcs, wt.to(dev), bias.to(dev), m, None if r is None else r.to(dev), relu)
+    err = rel_err(y.cpu(), ref)
+    assert err < TOL, err
+
+
+@pytest.mark.parametrize("r,c", [(56, 8), (7, 256), (130, 64)])
+def test_attention_rows(dev, r, c):
+    from relpose_gnn_amd import ops
+    gtp = _rand(r, 3 * c, seed=9, scale=1.5)
+    g, th, ph = gtp[:, :c], gtp[:, c:2 * c], gtp[:, 2 * c:]
+    a = torch.softmax(ph.unsqueeze(2) * th.unsqueeze(1), dim=-1)
+    ref = torch.bmm(a, g.unsqueeze(2)).squeeze(2)
+    err = rel_err(ops.attention_rows(gtp.to(dev)).cpu(), ref)
+    assert err < TOL, err
+
+
+@pytest.mark.parametrize("n_nodes,b,d", [(8, 4, 64), (8, 32, 2048), (4, 1, 128)])
+def test_scatter_mean_bit_exact(dev, n_nodes, b, d):
+    from relpose_gnn_amd import ops
+    from oracle.posenet_ref import scatter_mean
+    ei = _fc_edges(n_nodes, b)
+    n = n_nodes * b
+    msg = _rand(ei.shape[1], d, seed=13)
+    g = ops.graph_prepare(ei.to(dev), n)
+    out = ops.scatter_mean(msg.to(dev), g["rowptr"], g["perm"], n).cpu()
+    ref = scatter_mean(msg, ei[1], n)
+    assert torch.equal(out, ref), rel_err(out, ref)
+
+
+def test_scatter_mean_isolated_nodes(dev):
+    from relpose_gnn_amd import ops
+    from oracle.posenet_ref import scatter_mean
+    ei = torch.tensor([[0, 1, 2, 2], [3, 3, 3, 0]])
+    msg = _rand(4, 32, seed=1)
+    g = ops.graph_prepare(ei.to(dev), 6)
+    out = ops.scatter_mean(msg.to(dev), g["rowptr"], g["perm"], 6).cpu()
+    assert torch.equal(out, scatter_mean(msg, ei[1], 6))
+    assert float(out[[1, 2, 4, 5]].abs().max()) == 0.0
+
+
+def test_pose_heads(dev):
+    from relpose_gnn_amd import ops
+    x, w6, b6 = _rand(61, 2048, seed=2), _rand(6, 2048, seed=3, scale=0.02), _rand(6, seed=4)
+    err = rel_err(ops.pose_heads(x.to(dev), w6.to(dev), b6.to(dev)).cpu(), F.linear(x, w6, b6))
+    assert err < TOL, err
+
+
+def test_bad_arguments_raise(dev):
+    from relpose_gnn_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.maxpool3x3s2_nhwc(torch.zeros(1, 4, 4, 8))                       # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        ops.maxpool3x3s2_nhwc(torch.zeros(1, 4, 4, 6, device=dev))           # c % 4 != 0
+    with pytest.raises(TypeError):
+        ops.pose_heads(torch.zeros(2, 8, device=dev, dtype=torch.float64), torch.zeros(6, 8, device=dev), torch.zeros(6, device=dev))
