@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Benchmark of the relpose-gnn inference hot path on MI355X: graphs/sec on synthetic 8-node fully-connected
+224x224 graphs (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A step = one forward of PoseNetX_R2 (ResNet34 encoder -> FC-graph GNN -> pose heads, R3 dims: D=2048,
+gnn_recursion=2, droprate=0, eval) over one batch of 32 graphs (256 images) per GPU -- BASELINE.json configs[1] --
+with the inputs already resident in HBM; for N>1 each rank runs its own batch (weak scaling, graphs are independent)
+and the predicted relative poses are all-gathered over RCCL every step.  Rank 0 prints ONE JSON line.
+
+The line also carries
+  roofline     for the dominant kernel (the implicit-GEMM f32-MFMA convolution): algorithmic FLOP of all its launches
+               in the timed steps / their summed HIP-event durations, against the 157.3 TFLOP/s f32 matrix peak;
+  cpu_baseline the CPU oracle (validated against the reference in this repo's build container) timed on this box's
+               host cores on a bounded sample of the same workload (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+F32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+HBM_PEAK_GBS = 8000.0
+NODES, IMG = 8, 224
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--graphs", type=int, default=32, help="graphs per step per GPU (configs[1]: 32)")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, budget_s: float):
+    """Oracle forward (PyTorch CPU fp32) on 4-graph batches of the same workload until ~budget_s of CPU time."""
+    from oracle import posenet_ref as O              # the checker, timed here as the reported CPU baseline
+    import relpose_gnn_amd.synth as S
+    threads = torch.get_num_threads()
+    g = 4
+    x = S.synth_images(NODES * g, IMG, IMG, seed=77)
+    ei = O.batch_edge_index(NODES, g)
+    O.posenet_forward(sd, x, ei, IMG, 2)             # warm-up
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        O.posenet_forward(sd, x, ei, IMG, 2)
+        iters += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or iters >= 50:
+            break
+    return {"value": round(g * iters / dt, 3), "unit": "graphs/s", "cores": threads, "kind": "port",
+            "sample": f"{iters} forwards of {g} graphs ({NODES * g} images 224x224), torch {torch.__version__} CPU fp32, "
+                      f"{threads} threads, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP kernels are the only compute path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd import ops
+    from relpose_gnn_amd.graph import fc_batch
+    from relpose_gnn_amd.posenet import PoseNetX_R2
+    from relpose_gnn_amd.resnet import resnet34
+    from relpose_gnn_amd.shard import gather_rows
+
+    D = 2048
+    model = PoseNetX_R2(resnet34(), droprate=0.0, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D,
+                        input_img_height=IMG, use_gnn=True, knn=-1, use_AP=True, gnn_recursion=2)
+    sd = S.synth_state_dict(S.posenet_r2_param_shapes(D, D, D), seed=1)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+
+    B = args.graphs
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn((NODES * B, 3 * IMG * IMG), generator=gen, device=dev, dtype=torch.float32)
+    data = fc_batch(x, NODES)          # edge_index / batch built on x's device
+    counts = [B] * world
+
+    def step():
+        _, rel, _ = model(data)
+        if world > 1:
+            return gather_rows(rel.view(B, NODES * (NODES - 1), 6), counts)
+        return rel
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+
+    timing = not args.no_kernel_timing
+    if timing:
+        ops.timing_read()              # drop anything recorded so far
+        ops.timing_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kt = None
+    if timing:
+        ops.timing_enable(False)
+        kt = ops.timing_read()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert out.shape[-1] == 6 and bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        graphs = B * world * args.steps
+        line = {
+            "metric": "graphs/sec (8-node fully-connected, 224x224)", "value": round(graphs / elapsed, 2),
+            "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: batch=32 8-node fully-connected graphs per GPU, 224x224 RGB, "
+                                   "fp32, ResNet34 + GNN (D=2048, gnn_recursion=2, droprate=0, eval), random-init weights",
+                       "graphs_per_step_per_gpu": B, "nodes_per_graph": NODES, "edges_per_graph": NODES * (NODES - 1),
+                       "image": [IMG, IMG], "parallelism": f"graph-sharded x{world}, all-gather of rel poses per step"},
+        }
+        if kt is not None and kt["conv"]["launches"]:
+            c = kt["conv"]
+            ach = c["work"] / (c["ms"] * 1e-3) / 1e12
+            line["roofline"] = {
+                "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                "kernel": "gemm_tile_kernel<ConvLoader> (implicit-GEMM conv+BN+ReLU, v_mfma_f32_32x32x2_f32)",
+                "launches": c["launches"], "avg_launch_ms": round(c["ms"] / c["launches"], 4),
+                "alg_gflop_per_launch": round(c["work"] / c["launches"] / 1e9, 3),
+                "share_of_step_time": round(c["ms"] / (1e3 * elapsed), 4),
+            }
+            other = {}
+            for k in ("linear", "attention", "scatter"):
+                v = kt[k]
+                if not v["launches"]:
+                    continue
+                if k == "scatter":
+                    gbs = v["work"] / (v["ms"] * 1e-3) / 1e9
+                    other[k] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(gbs / HBM_PEAK_GBS, 4), "launches": v["launches"],
+                                "avg_launch_ms": round(v["ms"] / v["launches"], 5)}
+                else:
+                    tf = v["work"] / (v["ms"] * 1e-3) / 1e12
+                    other[k] = {"achieved": round(tf, 2), "unit": "TFLOP/s", "launches": v["launches"],
+                                "avg_launch_ms": round(v["ms"] / v["launches"], 5),
+                                "share_of_step_time": round(v["ms"] / (1e3 * elapsed), 4)}
+            line["other_kernels"] = other
+        if world == 1 and args.cpu_baseline_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(sd, args.cpu_baseline_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -92,7 +92,7 @@ extern "C" int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors
     if ((rc = rpg_nchw3_to_nhwc4_f32(x_nchw, in4, n, h, w, stream)) != RPG_OK) return rc;
     // stem: conv7x7/2 pad 3 (3 -> planes[0], input channels padded to 4 with zero weights) + BN + ReLU
     if ((rc = rpg::launch_conv(in4, tensors[ti], tensors[ti + 1], tensors[ti + 2], nullptr, stem, n, h, w, 4,
-                               planes[0], 7, 7, 2, 3, 1, s)) != RPG_OK)
+                               planes[0], 7, 7, 2, 3, 1, s, 3)) != RPG_OK)
         return rc;
     ti += 3;
     if ((rc = rpg_maxpool3x3s2_nhwc_f32(stem, buf[0], n, p.h1, p.w1, planes[0], stream)) != RPG_OK) return rc;

@@ -318,7 +318,7 @@ namespace rpg {
 
 int launch_conv(const float* x, const float* w, const float* scale, const float* shift, const float* residual,
                 float* y, int n, int h, int wd, int cin, int cout, int kh, int kw, int stride, int pad, int relu,
-                hipStream_t s) {
+                hipStream_t s, int alg_cin) {
     if (!x || !w || !y || n <= 0 || h <= 0 || wd <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 ||
         stride <= 0 || pad < 0 || (cin & 3) || !aligned16(x) || !aligned16(w) || !aligned16(y))
         return RPG_ERR_BAD_ARG;
@@ -331,7 +331,7 @@ int launch_conv(const float* x, const float* w, const float* scale, const float*
     Epilogue ep{scale, shift, residual, y, cout, relu};
     const int slot = timing_begin(RPG_TIMER_CONV, s);
     launch_tiles<ConvLoader, ConvArgs>(a, w, (int)K, (int)M, cout, (int)K, ep, s);
-    timing_end(slot, 2.0 * (double)M * cout * (double)K, s);
+    timing_end(slot, 2.0 * (double)M * cout * (double)kh * kw * (alg_cin > 0 ? alg_cin : cin), s);
     RPG_CHECK_LAUNCH("conv2d_bn_act");
     return RPG_OK;
 }

@@ -39,7 +39,7 @@ struct GatherSrc {
 
 int launch_conv(const float* x, const float* w, const float* scale, const float* shift, const float* residual,
                 float* y, int n, int h, int wd, int cin, int cout, int kh, int kw, int stride, int pad, int relu,
-                hipStream_t s);
+                hipStream_t s, int alg_cin = 0 /* channels counted as algorithmic work; 0 = cin */);
 int launch_linear(const GatherSrc& src, const float* weight, const float* bias, const float* residual, float* out,
                   int m, int n_out, int relu, hipStream_t s);
 
