@@ -145,6 +145,18 @@ int rpg_timing_enable(int enable);
  * (FLOP for CONV/LINEAR/ATTENTION, bytes for SCATTER).                                          */
 int rpg_timing_read(double* ms, long long* launches, double* work);
 
+/* Tuning knobs of the f32 MFMA tile engine (benchmarking aid; defaults are the tuned choice).
+ *   RPG_TUNE_TILE      -1 automatic (default) | 0: 128x128 | 1: 256x64 | 2: 64x64 workgroup tile
+ *   RPG_TUNE_BK        K-step: 0 automatic (default: 32 for the 128x128 tile, else 16) | 16 | 32
+ *   RPG_TUNE_EPILOGUE  1: LDS-transposed 16-byte epilogue (default) | 0: direct 4-byte epilogue
+ *   RPG_TUNE_STREAMK   1: stream-K pass for the tiles that do not fill a round of resident workgroups
+ *                      (default; uses a library-owned per-stream scratch buffer, grown on demand) | 0: off  */
+#define RPG_TUNE_TILE 0
+#define RPG_TUNE_BK 1
+#define RPG_TUNE_EPILOGUE 2
+#define RPG_TUNE_STREAMK 3
+int rpg_set_tuning(int key, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,16 +15,17 @@
 // addressing is per-row, and the padded pitch rules out LDS-DMA); the loads for step t+1 are issued before
 // the MFMAs of step t and written to the other buffer after them, one barrier per step.
 // Workgroup ids are remapped so that the tiles sharing an A row-panel run on one XCD (shared L2).
+#include <map>
+#include <mutex>
+
 #include "rpg_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 16;
-constexpr int LDS_LD = BK + 4;
 constexpr int NTHREADS = 256;
-constexpr int ROWS_PER_PASS = NTHREADS / (BK / 4);   // 64 rows of 4 float4 slots
+// K-step BK in {16, 32}: LDS pitch BK+4 floats; a staging pass covers NTHREADS / (BK/4) rows of BK/4 float4 slots.
 
 struct Epilogue {
     const float* scale;      // per output column, or null
@@ -42,23 +43,24 @@ __device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// A-operand loaders.  Each thread owns one 4-float k-slot (tid & 3) of R rows (tid >> 2) + 64 j.
+// A-operand loaders.  Each thread owns one 4-float k-slot (tid % SLOTS) of R rows (tid / SLOTS) + ROWS_PER_PASS j.
 // ------------------------------------------------------------------------------------------------
 struct ConvArgs {
     const float* x;
     int H, W, Cin, KH, KW, stride, pad, Ho, Wo;
 };
 
-template <int R>
+template <int R, int BK>
 struct ConvLoader {
+    static constexpr int SLOTS = BK / 4, ROWS_PER_PASS = NTHREADS / SLOTS;
     const float* img[R];
     int hi0[R], wi0[R];
     int H, W, Cin, KH, KW;
     int kh, kw, c;
 
-    __device__ __forceinline__ void init(const ConvArgs& a, int m0, int M, int tid) {
+    __device__ __forceinline__ void init(const ConvArgs& a, int m0, int M, int tid, int kbase) {
         H = a.H; W = a.W; Cin = a.Cin; KH = a.KH; KW = a.KW;
-        const int r0 = tid >> 2;
+        const int r0 = tid / SLOTS;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int m = m0 + r0 + ROWS_PER_PASS * j;
@@ -76,7 +78,7 @@ struct ConvLoader {
                 wi0[j] = 0;
             }
         }
-        const int k0 = 4 * (tid & 3);
+        const int k0 = kbase + 4 * (tid % SLOTS);
         c = k0 % Cin;
         const int t = k0 / Cin;
         kw = t % KW;
@@ -106,16 +108,17 @@ struct GatherArgs {
     int w0, w01, K;    // segment boundaries along k: [0,w0) [w0,w01) [w01,K)
 };
 
-template <int R>
+template <int R, int BK>
 struct GatherLoader {
+    static constexpr int SLOTS = BK / 4, ROWS_PER_PASS = NTHREADS / SLOTS;
     const float* r0p[R];
     const float* r1p[R];
     const float* r2p[R];
     int w0, w01, K, k;
 
-    __device__ __forceinline__ void init(const GatherArgs& a, int m0, int M, int tid) {
+    __device__ __forceinline__ void init(const GatherArgs& a, int m0, int M, int tid, int kbase) {
         w0 = a.w0; w01 = a.w01; K = a.K;
-        const int r0 = tid >> 2;
+        const int r0 = tid / SLOTS;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int m = m0 + r0 + ROWS_PER_PASS * j;
@@ -133,7 +136,7 @@ struct GatherLoader {
                 }
             }
         }
-        k = 4 * (tid & 3);
+        k = kbase + 4 * (tid % SLOTS);
     }
     __device__ __forceinline__ void fetch(float4 (&v)[R]) const {
 #pragma unroll
@@ -150,47 +153,41 @@ struct GatherLoader {
 };
 
 // ------------------------------------------------------------------------------------------------
-// The tile kernel
+// The tile engine
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, template <int> class Loader, class Args>
-__global__ __launch_bounds__(NTHREADS) void gemm_tile_kernel(Args args, const float* __restrict__ Wt, int ldw,
-                                                             int M, int N, int K, Epilogue ep, int tiles_n) {
+template <int BM, int BN, int WM, int WN, int BK>
+struct Tile {
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
-    constexpr int RA = BM / ROWS_PER_PASS, RW = BN / ROWS_PER_PASS;
+    static constexpr int LDS_LD = BK + 4;
+    static constexpr int SLOTS = BK / 4, ROWS_PER_PASS = NTHREADS / SLOTS;
+    static constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
+    static constexpr int RA = BM / ROWS_PER_PASS, RW = BN / ROWS_PER_PASS;
+    static constexpr int STAGE = (BM + BN) * LDS_LD;                    // floats per LDS buffer
+    static constexpr int LDS_BYTES = 2 * STAGE * (int)sizeof(float);
     static_assert(FM >= 1 && FN >= 1 && RA >= 1 && RW >= 1, "tile too small");
-    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_LD];
+};
 
-    // XCD-aware, bijective remap of the linear workgroup id: workgroup b runs on XCD b % 8, so give every
-    // XCD a contiguous run of tiles (tile_n fastest => neighbours share the A row panel in that XCD's L2).
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r = nwg & 7;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    const int m0 = (tile / tiles_n) * BM;
-    const int n0 = (tile % tiles_n) * BN;
-
+// acc += A[m0.., ks*BK .. ke*BK) * W[n0.., same k)^T.  Ends with a workgroup barrier: LDS is free afterwards.
+template <int BM, int BN, int WM, int WN, int BK, template <int, int> class Loader, class Args>
+__device__ __forceinline__ void tile_mainloop(const Args& args, const float* __restrict__ Wt, int ldw, int M, int N,
+                                              int K, int m0, int n0, int ks, int ke, float* lds,
+                                              f32x16 (&acc)[Tile<BM, BN, WM, WN, BK>::FM][Tile<BM, BN, WM, WN, BK>::FN]) {
+    using T = Tile<BM, BN, WM, WN, BK>;
+    constexpr int LDS_LD = T::LDS_LD, ROWS_PER_PASS = T::ROWS_PER_PASS, FM = T::FM, FN = T::FN, RA = T::RA, RW = T::RW;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int slot = tid & 3, srow = tid >> 2;
+    const int slot = tid % T::SLOTS, srow = tid / T::SLOTS;
 
-    Loader<RA> la;
-    la.init(args, m0, M, tid);
+    Loader<RA, BK> la;
+    la.init(args, m0, M, tid, ks * BK);
     const float* wrow[RW];
 #pragma unroll
     for (int j = 0; j < RW; ++j) {
         const int n = n0 + srow + ROWS_PER_PASS * j;
         wrow[j] = (n < N) ? Wt + (size_t)n * ldw : nullptr;
     }
-    int kw_ = 4 * slot;   // this thread's k position in W
-
-    f32x16 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int kw_ = ks * BK + 4 * slot;   // this thread's k position in W
 
     float4 ra[RA], rw[RW];
     auto fetch_w = [&]() {
@@ -198,7 +195,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tile_kernel(Args args, const fl
         for (int j = 0; j < RW; ++j) rw[j] = ld4_or_zero(wrow[j] + kw_, (wrow[j] != nullptr) && (kw_ < K));
     };
     auto stage = [&](int buf) {
-        float* As = lds[buf];
+        float* As = lds + buf * T::STAGE;
         float* Ws = As + BM * LDS_LD;
 #pragma unroll
         for (int j = 0; j < RA; ++j)
@@ -213,20 +210,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tile_kernel(Args args, const fl
     stage(0);
     __syncthreads();
 
-    const int nk = (K + BK - 1) / BK;
     const int a_off = (wm * FM * 32 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
     const int b_off = (BM + wn * FN * 32 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
-
-    for (int kt = 0; kt < nk; ++kt) {
+    const int nsteps = ke - ks;
+    for (int kt = 0; kt < nsteps; ++kt) {
         const int cur = kt & 1;
-        const bool more = (kt + 1 < nk);
+        const bool more = (kt + 1 < nsteps);
         if (more) {
             la.advance();
             kw_ += BK;
             la.fetch(ra);
             fetch_w();
         }
-        const float* L = lds[cur];
+        const float* L = lds + cur * T::STAGE;
 #pragma unroll
         for (int kb = 0; kb < BK; kb += 8) {
             float av[FM][4], bv[FN][4];
@@ -251,63 +247,317 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tile_kernel(Args args, const fl
         if (more) stage(cur ^ 1);
         __syncthreads();
     }
+}
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int n = n0 + (wn * FN + j) * 32 + col_l;
-        if (n >= N) continue;
-        const float sc = ep.scale ? ep.scale[n] : 1.f;
-        const float sh = ep.shift ? ep.shift[n] : 0.f;
+// Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).
+// EPI_LDS: each wave transposes its accumulators through a private LDS slab (the staging buffers are free after the
+// main loop's last barrier) so that global traffic is 16 bytes per lane: a row of the wave tile is FN*32 contiguous
+// floats = FN*8 lanes; residual loads / output stores are whole 128..256-byte row segments.  Slab: 32 rows x
+// (FN*32 + 4) floats per wave, processed once per FM fragment row.  Needs N % 4 == 0 and 16-byte aligned rows.
+template <int BM, int BN, int WM, int WN, int BK, bool EPI_LDS>
+__device__ __forceinline__ void tile_epilogue(float* lds, const Epilogue& ep, int m0, int n0, int M, int N,
+                                              f32x16 (&acc)[Tile<BM, BN, WM, WN, BK>::FM][Tile<BM, BN, WM, WN, BK>::FN]) {
+    using T = Tile<BM, BN, WM, WN, BK>;
+    constexpr int FM = T::FM, FN = T::FN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    if constexpr (EPI_LDS) {
+        constexpr int EW = FN * 32, EP = EW + 4, C4 = EW / 4, RPI = 64 / C4, NIT = 32 / RPI;
+        static_assert(4 * 32 * EP <= 2 * T::STAGE, "epilogue slab does not fit the staging LDS");
+        float* slab = lds + wave * (32 * EP);
+        const int c4 = lane % C4, r_in = lane / C4;
+        const int nb = n0 + wn * EW + 4 * c4;                 // first of this lane's 4 output columns
+        const bool n_ok = nb < N;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n_ok && ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + nb);
+        if (n_ok && ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + nb);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int mb = m0 + (wm * FM + i) * 32 + row_l;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                if (m < M) {
-                    float v = acc[i][j][e] * sc + sh;
-                    const size_t o = (size_t)m * ep.ldc + n;
-                    if (ep.residual) v += ep.residual[o];
-                    if (ep.relu) v = fmaxf(v, 0.f);
-                    ep.out[o] = v;
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    slab[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * EP + j * 32 + (lane & 31)] = acc[i][j][e];
+            __builtin_amdgcn_wave_barrier();
+            const int mb = m0 + (wm * FM + i) * 32;
+            float4 v[NIT], rs[NIT];
+#pragma unroll
+            for (int t = 0; t < NIT; ++t) {
+                const int row = r_in + RPI * t;
+                v[t] = *reinterpret_cast<const float4*>(&slab[row * EP + 4 * c4]);
+                rs[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ep.residual && n_ok && (mb + row) < M)
+                    rs[t] = *reinterpret_cast<const float4*>(ep.residual + (size_t)(mb + row) * ep.ldc + nb);
+            }
+#pragma unroll
+            for (int t = 0; t < NIT; ++t) {
+                const int m = mb + r_in + RPI * t;
+                float4 o;
+                o.x = v[t].x * sc.x + sh.x + rs[t].x;
+                o.y = v[t].y * sc.y + sh.y + rs[t].y;
+                o.z = v[t].z * sc.z + sh.z + rs[t].z;
+                o.w = v[t].w * sc.w + sh.w + rs[t].w;
+                if (ep.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                if (n_ok && m < M) *reinterpret_cast<float4*>(ep.out + (size_t)m * ep.ldc + nb) = o;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + (wn * FN + j) * 32 + col_l;
+            if (n >= N) continue;
+            const float sc = ep.scale ? ep.scale[n] : 1.f;
+            const float sh = ep.shift ? ep.shift[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int mb = m0 + (wm * FM + i) * 32 + row_l;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mb + (e & 3) + 8 * (e >> 2);
+                    if (m < M) {
+                        float v = acc[i][j][e] * sc + sh;
+                        const size_t o = (size_t)m * ep.ldc + n;
+                        if (ep.residual) v += ep.residual[o];
+                        if (ep.relu) v = fmaxf(v, 0.f);
+                        ep.out[o] = v;
+                    }
                 }
             }
         }
     }
 }
 
-enum TileShape { TILE_128x128, TILE_256x64, TILE_64x64 };
+template <int FM, int FN>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[FM][FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+}
 
-inline TileShape pick_tile(int M, int N) {
-    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+// Data-parallel kernel: one workgroup per output tile, whole K range.
+template <int BM, int BN, int WM, int WN, int BK, bool EPI_LDS, template <int, int> class Loader, class Args>
+__global__ __launch_bounds__(NTHREADS) void gemm_tile_kernel(Args args, const float* __restrict__ Wt, int ldw,
+                                                             int M, int N, int K, Epilogue ep, int tiles_n) {
+    using T = Tile<BM, BN, WM, WN, BK>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * STAGE floats
+    // XCD-aware, bijective remap of the linear workgroup id: workgroup b runs on XCD b % 8, so give every
+    // XCD a contiguous run of tiles (tile_n fastest => neighbours share the A row panel in that XCD's L2).
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+    f32x16 acc[T::FM][T::FN];
+    zero_acc(acc);
+    tile_mainloop<BM, BN, WM, WN, BK, Loader, Args>(args, Wt, ldw, M, N, K, m0, n0, 0, (K + BK - 1) / BK, lds, acc);
+    tile_epilogue<BM, BN, WM, WN, BK, EPI_LDS>(lds, ep, m0, n0, M, N, acc);
+}
+
+// Stream-K kernel for the tiles [tile_base, tile_base + R) that do not fill a whole round of resident workgroups:
+// their R*nk k-steps are dealt out evenly, `its_per` consecutive steps per workgroup.  A workgroup that covers a
+// tile's whole K range finishes it with the normal epilogue; otherwise it stores the raw partial tile [BM][BN] in
+// slab (g + t) of `partial` (g = workgroup, t = tile - tile_base: unique and increasing along the stream), and
+// streamk_fixup_kernel sums a tile's slabs in k order and applies the epilogue.
+template <int BM, int BN, int WM, int WN, int BK, bool EPI_LDS, template <int, int> class Loader, class Args>
+__global__ __launch_bounds__(NTHREADS) void gemm_streamk_kernel(Args args, const float* __restrict__ Wt, int ldw,
+                                                                int M, int N, int K, Epilogue ep, int tiles_n,
+                                                                int tile_base, int total_its, int nk, int its_per,
+                                                                float* __restrict__ partial) {
+    using T = Tile<BM, BN, WM, WN, BK>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int g = blockIdx.x;
+    int it = g * its_per;
+    const int it_end = min(it + its_per, total_its);
+    while (it < it_end) {
+        const int t = it / nk;
+        const int kb = it - t * nk;
+        const int ke = min(nk, kb + (it_end - it));
+        const int tile = tile_base + t;
+        const int m0 = (tile / tiles_n) * BM;
+        const int n0 = (tile % tiles_n) * BN;
+        f32x16 acc[T::FM][T::FN];
+        zero_acc(acc);
+        tile_mainloop<BM, BN, WM, WN, BK, Loader, Args>(args, Wt, ldw, M, N, K, m0, n0, kb, ke, lds, acc);
+        if (kb == 0 && ke == nk) {
+            tile_epilogue<BM, BN, WM, WN, BK, EPI_LDS>(lds, ep, m0, n0, M, N, acc);
+        } else {
+            const Epilogue raw{nullptr, nullptr, nullptr, partial + (size_t)(g + t) * (BM * BN), BN, 0};
+            tile_epilogue<BM, BN, WM, WN, BK, true>(lds, raw, 0, 0, BM, BN, acc);
+        }
+        __syncthreads();          // the epilogue slabs alias the staging buffers of the next segment
+        it += ke - kb;
+    }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(NTHREADS) void streamk_fixup_kernel(const float* __restrict__ partial, Epilogue ep, int M,
+                                                                 int N, int tiles_n, int tile_base, int nk, int its_per,
+                                                                 int vec) {
+    constexpr int C4 = BN / 4, CH = BM * C4 / NTHREADS;
+    const int t = blockIdx.x / CH, chunk = blockIdx.x % CH;
+    const int g_first = (t * nk) / its_per, g_last = ((t + 1) * nk - 1) / its_per;
+    if (g_first == g_last) return;                      // finished by a single workgroup with the normal epilogue
+    const int idx4 = chunk * NTHREADS + threadIdx.x;
+    const int row = idx4 / C4, c4 = idx4 % C4;
+    const float* p = partial + (size_t)(g_first + t) * (BM * BN) + row * BN + 4 * c4;
+    float4 s = *reinterpret_cast<const float4*>(p);
+    for (int g = g_first + 1; g <= g_last; ++g) {       // ascending k order
+        p += BM * BN;
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int tile = tile_base + t;
+    const int m = (tile / tiles_n) * BM + row;
+    const int n = (tile % tiles_n) * BN + 4 * c4;
+    if (m >= M || n >= N) return;
+    const size_t o = (size_t)m * ep.ldc + n;
+    if (vec) {
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f), rs = sh;
+        if (ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + n);
+        if (ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + n);
+        if (ep.residual) rs = *reinterpret_cast<const float4*>(ep.residual + o);
+        float4 v;
+        v.x = s.x * sc.x + sh.x + rs.x; v.y = s.y * sc.y + sh.y + rs.y;
+        v.z = s.z * sc.z + sh.z + rs.z; v.w = s.w * sc.w + sh.w + rs.w;
+        if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(ep.out + o) = v;
+    } else {
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+        for (int c = 0; c < 4 && n + c < N; ++c) {
+            float v = sv[c] * (ep.scale ? ep.scale[n + c] : 1.f) + (ep.shift ? ep.shift[n + c] : 0.f);
+            if (ep.residual) v += ep.residual[o + c];
+            if (ep.relu) v = fmaxf(v, 0.f);
+            ep.out[o + c] = v;
+        }
+    }
+}
+
+enum TileShape { TILE_128x128 = 0, TILE_256x64 = 1, TILE_64x64 = 2 };
+
+// Tuning knobs (rpg_set_tuning): -1 = automatic.
+int g_force_tile = -1;
+int g_bk = 0;                        // 0 = automatic: 32 for the 128x128 tile (2 workgroups/CU), else 16
+int g_epi_lds = 1;
+int g_streamk = 1;
+constexpr int SK_MIN_ITS = 8;        // at least this many k-steps per stream-K workgroup
+constexpr int SK_MIN_NK = 32;        // tiles with fewer k-steps are not worth splitting (fix-up traffic dominates)
+
+// Per-stream scratch for stream-K partial tiles (grown on demand; growth synchronises the device once).
+struct Scratch { float* p = nullptr; size_t bytes = 0; };
+std::mutex g_scratch_mu;
+std::map<hipStream_t, Scratch> g_scratch;
+float* get_scratch(hipStream_t s, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    Scratch& sc = g_scratch[s];
+    if (sc.bytes < bytes) {
+        if (sc.p) (void)hipFree(sc.p);
+        sc.p = nullptr; sc.bytes = 0;
+        const size_t want = bytes + bytes / 4;
+        if (hipMalloc(reinterpret_cast<void**>(&sc.p), want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        sc.bytes = want;
+    }
+    return sc.p;
+}
+
+int cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+    }
+    return n;
+}
+
+inline TileShape pick_tile(int M, int N, int K) {
+    if (g_force_tile >= 0 && g_force_tile <= 2) return (TileShape)g_force_tile;
     if (N <= 64) return (M >= 256 * 256) ? TILE_256x64 : TILE_64x64;
-    if (t128 >= 384) return TILE_128x128;     // >= 1.5 workgroups per CU of the big tile
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (t128 >= 384) return TILE_128x128;                 // >= 1.5 big tiles per CU
+    // fewer big tiles than CUs can balance: fine with stream-K when K is long enough to split, else go small
+    if (g_streamk && K >= 32 * SK_MIN_NK && (long)M * N >= 128L * 128 * 8) return TILE_128x128;
     return TILE_64x64;
 }
 
-template <template <int> class Loader, class Args>
+template <int BM, int BN, int WM, int WN, int BK, bool EPI, template <int, int> class Loader, class Args>
+int launch_one(const Args& args, const float* Wt, int ldw, int M, int N, int K, const Epilogue& ep, bool vec_ok,
+               hipStream_t s) {
+    using T = Tile<BM, BN, WM, WN, BK>;
+    auto kern = gemm_tile_kernel<BM, BN, WM, WN, BK, EPI, Loader, Args>;
+    auto kern_sk = gemm_streamk_kernel<BM, BN, WM, WN, BK, EPI, Loader, Args>;
+    constexpr int lds = T::LDS_BYTES;
+    static int occ = 0;               // resident workgroups per CU of this instantiation
+    if (!occ) {
+        if (lds > 64 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_sk), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        }
+        int o1 = 0, o2 = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, kern, NTHREADS, lds) != hipSuccess) o1 = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, kern_sk, NTHREADS, lds) != hipSuccess) o2 = 1;
+        occ = o1 < o2 ? o1 : o2;
+        if (occ < 1) occ = 1;
+        (void)hipGetLastError();
+    }
+    const int tn = (N + BN - 1) / BN, tm = (M + BM - 1) / BM;
+    const int tiles = tm * tn, nk = (K + BK - 1) / BK;
+    const int slots = cu_count() * occ;
+    int t_dp = tiles, its_per = 0, g_sk = 0;
+    float* partial = nullptr;
+    if (g_streamk && nk >= SK_MIN_NK && tiles % slots != 0) {
+        const int rem = tiles % slots;
+        const long total = (long)rem * nk;
+        its_per = (int)((total + slots - 1) / slots);
+        if (its_per < SK_MIN_ITS) its_per = SK_MIN_ITS;
+        g_sk = (int)((total + its_per - 1) / its_per);
+        if (g_sk > rem) {             // stream-K spreads the remainder over more workgroups than tiles: worth it
+            partial = get_scratch(s, (size_t)(g_sk + rem) * BM * BN * sizeof(float));
+            if (partial) t_dp = tiles - rem;
+        }
+    }
+    if (t_dp > 0)
+        hipLaunchKernelGGL(kern, dim3(t_dp), dim3(NTHREADS), lds, s, args, Wt, ldw, M, N, K, ep, tn);
+    if (t_dp < tiles) {
+        const int rem = tiles - t_dp;
+        hipLaunchKernelGGL(kern_sk, dim3(g_sk), dim3(NTHREADS), lds, s, args, Wt, ldw, M, N, K, ep, tn, t_dp, rem * nk, nk,
+                           its_per, partial);
+        constexpr int CH = BM * (BN / 4) / NTHREADS;
+        hipLaunchKernelGGL((streamk_fixup_kernel<BM, BN>), dim3(rem * CH), dim3(NTHREADS), 0, s, partial, ep, M, N, tn,
+                           t_dp, nk, its_per, vec_ok ? 1 : 0);
+    }
+    return 0;
+}
+
+template <int BK, bool EPI, template <int, int> class Loader, class Args>
+void launch_shape(TileShape t, const Args& args, const float* Wt, int ldw, int M, int N, int K, const Epilogue& ep,
+                  bool vec_ok, hipStream_t s) {
+    switch (t) {
+        case TILE_128x128: launch_one<128, 128, 2, 2, BK, EPI, Loader, Args>(args, Wt, ldw, M, N, K, ep, vec_ok, s); break;
+        case TILE_256x64: launch_one<256, 64, 4, 1, BK, EPI, Loader, Args>(args, Wt, ldw, M, N, K, ep, vec_ok, s); break;
+        default: launch_one<64, 64, 2, 2, BK, EPI, Loader, Args>(args, Wt, ldw, M, N, K, ep, vec_ok, s); break;
+    }
+}
+
+template <template <int, int> class Loader, class Args>
 int launch_tiles(const Args& args, const float* Wt, int ldw, int M, int N, int K, const Epilogue& ep, hipStream_t s) {
-    switch (pick_tile(M, N)) {
-        case TILE_128x128: {
-            const int tn = (N + 127) / 128, tm = (M + 127) / 128;
-            hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 2, 2, Loader, Args>), dim3(tm * tn), dim3(NTHREADS), 0, s,
-                               args, Wt, ldw, M, N, K, ep, tn);
-            break;
-        }
-        case TILE_256x64: {
-            const int tn = (N + 63) / 64, tm = (M + 255) / 256;
-            hipLaunchKernelGGL((gemm_tile_kernel<256, 64, 4, 1, Loader, Args>), dim3(tm * tn), dim3(NTHREADS), 0, s,
-                               args, Wt, ldw, M, N, K, ep, tn);
-            break;
-        }
-        default: {
-            const int tn = (N + 63) / 64, tm = (M + 63) / 64;
-            hipLaunchKernelGGL((gemm_tile_kernel<64, 64, 2, 2, Loader, Args>), dim3(tm * tn), dim3(NTHREADS), 0, s,
-                               args, Wt, ldw, M, N, K, ep, tn);
-            break;
-        }
+    const TileShape t = pick_tile(M, N, K);
+    const int bk = g_bk ? g_bk : ((t == TILE_128x128 && K >= 256) ? 32 : 16);
+    // 16-byte epilogue accesses need 4-column groups: N % 4 == 0 and 16-byte aligned rows
+    const bool vec_ok = (N % 4 == 0) && (ep.ldc % 4 == 0) && rpg::aligned16(ep.out) &&
+                        (!ep.residual || rpg::aligned16(ep.residual)) && (!ep.scale || rpg::aligned16(ep.scale)) &&
+                        (!ep.shift || rpg::aligned16(ep.shift));
+    const bool epi = g_epi_lds && vec_ok;
+    if (bk == 32) {
+        if (epi) launch_shape<32, true, Loader, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
+        else launch_shape<32, false, Loader, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
+    } else {
+        if (epi) launch_shape<16, true, Loader, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
+        else launch_shape<16, false, Loader, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
     }
     return 0;
 }
@@ -385,4 +635,14 @@ extern "C" int rpg_linear_gather_f32(int n_src, const float* const* a, const int
         src.width[i] = width[i];
     }
     return rpg::launch_linear(src, weight, bias, residual, out, m, n_out, relu, rpg::as_stream(stream));
+}
+
+extern "C" int rpg_set_tuning(int key, int value) {
+    switch (key) {
+        case RPG_TUNE_TILE: g_force_tile = value; return RPG_OK;
+        case RPG_TUNE_BK: if (value != 0 && value != 16 && value != 32) return RPG_ERR_BAD_ARG; g_bk = value; return RPG_OK;
+        case RPG_TUNE_EPILOGUE: g_epi_lds = value != 0; return RPG_OK;
+        case RPG_TUNE_STREAMK: g_streamk = value != 0; return RPG_OK;
+        default: return RPG_ERR_BAD_ARG;
+    }
 }

@@ -157,3 +157,10 @@ def timing_read() -> Dict[str, Dict[str, float]]:
     ms, cnt, work = (C.c_double * n)(), (C.c_longlong * n)(), (C.c_double * n)()
     L.check(L.lib().rpg_timing_read(ms, cnt, work), "timing_read")
     return {name: {"ms": ms[i], "launches": int(cnt[i]), "work": work[i]} for i, name in enumerate(L.TIMER_NAMES)}
+
+
+TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK = 0, 1, 2, 3
+
+
+def set_tuning(key: int, value: int) -> None:
+    L.check(L.lib().rpg_set_tuning(key, value), "set_tuning")

@@ -219,3 +219,47 @@ def test_bad_arguments_raise(dev):
         ops.maxpool3x3s2_nhwc(torch.zeros(1, 4, 4, 6, device=dev))           # c % 4 != 0
     with pytest.raises(TypeError):
         ops.pose_heads(torch.zeros(2, 8, device=dev, dtype=torch.float64), torch.zeros(6, 8, device=dev), torch.zeros(6, device=dev))
+
+
+@pytest.mark.parametrize("bk", [16, 32])
+@pytest.mark.parametrize("epi", [0, 1])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
+@pytest.mark.parametrize("streamk", [0, 1])
+def test_tile_engine_variants(dev, bk, epi, tile, streamk):
+    """Every (K-step, epilogue, workgroup-tile) variant of the MFMA tile engine on a conv with ragged M, K tail,
+    residual + ReLU, and on a 3-source gathered Linear whose N is not a tile multiple."""
+    from relpose_gnn_amd import ops
+    try:
+        ops.set_tuning(ops.TUNE_BK, bk)
+        ops.set_tuning(ops.TUNE_EPILOGUE, epi)
+        ops.set_tuning(ops.TUNE_TILE, tile)
+        ops.set_tuning(ops.TUNE_STREAMK, streamk)
+        n, h, w, cin, cout = 3, 13, 17, 24, 72            # M = 663, K = 216 (not a multiple of 16/32), N = 72
+        x = _rand(n, cin, h, w, seed=1)
+        wt = _rand(cout, cin, 3, 3, seed=2, scale=(2.0 / (cin * 9)) ** 0.5)
+        scale = torch.rand(cout, generator=torch.Generator().manual_seed(3)) + 0.5
+        shift = _rand(cout, seed=4, scale=0.1)
+        r = _rand(n, cout, h, w, seed=5)
+        ref = F.relu(F.conv2d(x, wt, None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + r)
+        y = ops.conv2d_bn_act_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev),
+                                   scale.to(dev), shift.to(dev), r.permute(0, 2, 3, 1).contiguous().to(dev), stride=1, pad=1,
+                                   relu=True)
+        assert rel_err(y.cpu().permute(0, 3, 1, 2), ref) < TOL
+        g0 = torch.Generator().manual_seed(5)
+        m, widths, n_out = 333, (40, 24, 536), 100         # K = 600: every tile is split over several stream-K segments
+        srcs, cat = [], []
+        for i, wd in enumerate(widths):
+            a = _rand(50, wd, seed=10 + i)
+            idx = torch.randint(0, 50, (m,), generator=g0)
+            srcs.append((a.to(dev), idx.to(dev)))
+            cat.append(a[idx])
+        k = sum(widths)
+        wl, bias, res = _rand(n_out, k, seed=20, scale=k ** -0.5), _rand(n_out, seed=21), _rand(m, n_out, seed=22)
+        ref = F.linear(torch.cat(cat, 1), wl, bias) + res
+        out = ops.linear_gather(srcs, wl.to(dev), bias.to(dev), m, res.to(dev), False)
+        assert rel_err(out.cpu(), ref) < TOL
+    finally:
+        ops.set_tuning(ops.TUNE_BK, 0)
+        ops.set_tuning(ops.TUNE_EPILOGUE, 1)
+        ops.set_tuning(ops.TUNE_TILE, -1)
+        ops.set_tuning(ops.TUNE_STREAMK, 1)

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the implicit-GEMM conv / gathered GEMM kernels at the ResNet34 / GNN shapes of BASELINE configs[1]
+(256 images, 1792 edges).  Prints TFLOP/s per shape (HIP-event timed, median of reps).  Usage on the GPU box:
+    python tools/conv_bench.py [--reps 20] [--only l3]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from relpose_gnn_amd import ops  # noqa: E402
+
+SHAPES = [  # name, n, h, w, cin, cout, k, stride, pad, residual
+    ("stem", 256, 224, 224, 4, 64, 7, 2, 3, False),
+    ("l1.c1", 256, 56, 56, 64, 64, 3, 1, 1, False),
+    ("l1.c2", 256, 56, 56, 64, 64, 3, 1, 1, True),
+    ("l2.c1", 256, 28, 28, 128, 128, 3, 1, 1, False),
+    ("l2.c2", 256, 28, 28, 128, 128, 3, 1, 1, True),
+    ("l2.ds", 256, 56, 56, 64, 128, 1, 2, 0, False),
+    ("l3.c1", 256, 14, 14, 256, 256, 3, 1, 1, False),
+    ("l3.c2", 256, 14, 14, 256, 256, 3, 1, 1, True),
+    ("l4.c1", 256, 7, 7, 512, 512, 3, 1, 1, False),
+    ("l4.c2", 256, 7, 7, 512, 512, 3, 1, 1, True),
+]
+LINEAR = [  # name, m, widths, n_out
+    ("edge0", 1792, (2048, 2048, 2048), 2048),
+    ("edge2", 1792, (2048,), 2048),
+    ("gtp", 1792, (2048,), 768),
+    ("attW", 1792, (256,), 2048),
+    ("upd0", 256, (2048, 2048), 2048),
+    ("fc", 256, (512,), 2048),
+]
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--bk", type=int, default=0)
+    ap.add_argument("--epi", type=int, default=1)
+    ap.add_argument("--tile", type=int, default=-1)
+    ap.add_argument("--sk", type=int, default=1)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    ops.set_tuning(ops.TUNE_BK, args.bk)
+    ops.set_tuning(ops.TUNE_EPILOGUE, args.epi)
+    ops.set_tuning(ops.TUNE_TILE, args.tile)
+    ops.set_tuning(ops.TUNE_STREAMK, args.sk)
+    print(f"# bk={args.bk} epi={args.epi} tile={args.tile} streamk={args.sk}", flush=True)
+    for name, n, h, w, cin, cout, k, s, p, res in SHAPES:
+        if args.only and args.only not in name:
+            continue
+        x = torch.randn(n, h, w, cin, device=dev)
+        wt = torch.randn(cout, k, k, cin, device=dev) * (2.0 / (cin * k * k)) ** 0.5
+        sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.1
+        ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        r = torch.randn(n, ho, wo, cout, device=dev) if res else None
+        med, best = timeit(lambda: ops.conv2d_bn_act_nhwc(x, wt, sc, sh, r, stride=s, pad=p, relu=True), args.reps)
+        fl = 2.0 * n * ho * wo * cout * k * k * (3 if name == "stem" else cin)
+        print(f"conv {name:6s} M={n*ho*wo:8d} N={cout:4d} K={k*k*cin:5d}  {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF (best {fl/best/1e9:6.1f})", flush=True)
+    for name, m, widths, n_out in LINEAR:
+        if args.only and args.only not in name:
+            continue
+        srcs = []
+        for wd in widths:
+            a = torch.randn(256 if len(widths) > 1 and m > 256 else m, wd, device=dev)
+            idx = torch.randint(0, a.shape[0], (m,), device=dev) if a.shape[0] != m else None
+            srcs.append((a, idx))
+        kk = sum(widths)
+        wt = torch.randn(n_out, kk, device=dev) * kk ** -0.5
+        b = torch.randn(n_out, device=dev)
+        med, best = timeit(lambda: ops.linear_gather(srcs, wt, b, m, relu=True), args.reps)
+        fl = 2.0 * m * n_out * kk
+        print(f"lin  {name:6s} M={m:8d} N={n_out:4d} K={kk:5d}  {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF (best {fl/best/1e9:6.1f})", flush=True)
+
+
+if __name__ == "__main__":
+    main()
