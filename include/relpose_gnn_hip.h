@@ -90,6 +90,16 @@ int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors, const int
 int rpg_graph_prepare(const int64_t* edge_index, int e, int n, int64_t* ends, int32_t* rowptr,
                       int32_t* cursor, int32_t* perm, int32_t* status, void* stream);
 
+/* torch_cluster.knn_graph(x, k, batch, loop=False, flow='source_to_target') (posenet.py:1043-1050): for every node
+ * the k nearest OTHER nodes of its graph by squared Euclidean distance (k+1 nearest including itself by
+ * (distance, index), self match dropped).  x [n][d]; batch [n] int64 graph id per node, nodes of a graph contiguous,
+ * NULL = one graph.  edge_index: capacity [2][n*(k+1)], row stride n*(k+1); the first *total columns are valid:
+ * row 0 = neighbour (source), row 1 = query node (target), grouped by target in node order, nearest first.
+ * cand [n][k+1], cnt [n] scratch; total [1]; status [1] += graphs larger than 2048 nodes (unsupported).
+ * k <= 64.                                                                                                   */
+int rpg_knn_graph_f32(const float* x, const int64_t* batch, int n, int d, int k, int64_t* edge_index,
+                      int32_t* cand, int32_t* cnt, int32_t* total, int32_t* status, void* stream);
+
 /* compute_edge_features (posenet.py:999-1019): out[e] = [x[min(s,t)], x[max(s,t)]], [e][2d]. */
 int rpg_edge_concat_gather_f32(const float* x, const int64_t* edge_index, int e, int d, float* out, void* stream);
 

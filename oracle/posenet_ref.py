@@ -179,17 +179,39 @@ def gnn_layer(sd: Dict[str, Tensor], p: str, x: Tensor, edge_index: Tensor, e: T
     return x_new, e_new
 
 
+def knn_graph(x: Tensor, k: int, batch: Optional[Tensor] = None) -> Tensor:
+    """torch_cluster 1.5.9 ``knn_graph(x, k, batch, loop=False, flow='source_to_target')`` restated (call sites
+    posenet.py:1044-1050).  PARITY UNPINNED for this function: torch_cluster is not installed and the reference holds no
+    vectors for it; this follows the published algorithm -- for every node the k+1 nearest nodes of its own graph by
+    squared Euclidean distance (ties: lower index first), the self match removed (``row != col``); row 0 = neighbour
+    (message source), row 1 = the query node (target); grouped by target in node order, nearest first."""
+    n = x.shape[0]
+    batch = torch.zeros(n, dtype=torch.int64) if batch is None else batch
+    src: List[int] = []
+    dst: List[int] = []
+    for i in range(n):
+        idx = (batch == batch[i]).nonzero().flatten()
+        d = ((x[idx] - x[i]) ** 2).sum(1)
+        order = torch.sort(d, stable=True).indices[: k + 1]
+        for j in idx[order].tolist():
+            if j != i:
+                src.append(j)
+                dst.append(i)
+    return torch.tensor([src, dst], dtype=torch.int64)
+
+
 def gnn_forward(sd: Dict[str, Tensor], x: Tensor, edge_index: Tensor, gnn_recursion: int = 2,
-                stages: Optional[Dict[str, Tensor]] = None) -> Tuple[Tensor, Tensor]:
-    """Everything after the encoder: posenet.py:1052-1091 with use_gnn, use_AP, droprate=0, knn<=0."""
+                stages: Optional[Dict[str, Tensor]] = None, use_AP: bool = True) -> Tuple[Tensor, Tensor]:
+    """Everything after the encoder: posenet.py:1052-1091 with use_gnn, droprate=0 (edge_index already final)."""
     e = F.relu(F.linear(edge_concat(x, edge_index), sd["proj_edge.weight"], sd["proj_edge.bias"]))
     if stages is not None:
         stages["proj_edge"] = e
     for r in range(gnn_recursion):          # same gnn1 weights every recursion (:1061-1069)
         x, e = gnn_layer(sd, "gnn1.", x, edge_index, e, stages, f"r{r}.")
         x, e = F.relu(x), F.relu(e)
-    abs_pose = torch.cat([F.linear(x, sd["fc_xyz.weight"], sd["fc_xyz.bias"]),
-                          F.linear(x, sd["fc_wpqr.weight"], sd["fc_wpqr.bias"])], dim=1)
+    h = x if use_AP else edge_concat(x, edge_index)                    # posenet.py:1077-1083
+    abs_pose = torch.cat([F.linear(h, sd["fc_xyz.weight"], sd["fc_xyz.bias"]),
+                          F.linear(h, sd["fc_wpqr.weight"], sd["fc_wpqr.bias"])], dim=1)
     rel_pose = torch.cat([F.linear(e, sd["fc_xyz_R.weight"], sd["fc_xyz_R.bias"]),
                           F.linear(e, sd["fc_wpqr_R.weight"], sd["fc_wpqr_R.bias"])], dim=1)
     return abs_pose, rel_pose
@@ -197,13 +219,21 @@ def gnn_forward(sd: Dict[str, Tensor], x: Tensor, edge_index: Tensor, gnn_recurs
 
 @torch.no_grad()
 def posenet_forward(sd: Dict[str, Tensor], x_flat: Tensor, edge_index: Tensor, img_h: int,
-                    gnn_recursion: int = 2, stages: Optional[Dict[str, Tensor]] = None
+                    gnn_recursion: int = 2, stages: Optional[Dict[str, Tensor]] = None, use_attention: bool = False,
+                    use_AP: bool = True, knn: int = -1, k: Optional[int] = None, batch: Optional[Tensor] = None
                     ) -> Tuple[Tensor, Tensor, Tensor]:
-    """data.x [N,3*H*W], data.edge_index [2,E] -> (abs[N,6], rel[E,6], edge_index)."""
+    """data.x [N,3*H*W], data.edge_index [2,E] -> (abs, rel[E,6], edge_index) -- posenet.py:1033-1091, droprate=0."""
     x = x_flat.view(x_flat.shape[0], 3, img_h, -1).contiguous()       # posenet.py:1035
     feat = resnet34_forward(sd, x, stages=stages)
-    abs_pose, rel_pose = gnn_forward(sd, feat, edge_index, gnn_recursion, stages)
-    return abs_pose, rel_pose, edge_index
+    if use_attention:                                                  # posenet.py:1040-1041
+        feat = attention_block(sd, "att.", feat)
+    edge_index_knn = knn_graph(feat, k, batch) if k is not None else None          # :1043-1044
+    if knn > 0:                                                        # :1047-1050
+        edge_index = knn_graph(feat, knn, batch)
+    elif k is not None:
+        edge_index = knn_graph(feat, k, batch)
+    abs_pose, rel_pose = gnn_forward(sd, feat, edge_index, gnn_recursion, stages, use_AP)
+    return abs_pose, rel_pose, (edge_index_knn if k is not None else edge_index)   # :1088-1091
 
 
 # --------------------------------------------------------------------------- #

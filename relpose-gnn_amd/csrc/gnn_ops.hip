@@ -151,8 +151,8 @@ __global__ __launch_bounds__(NT) void attention_rows_kernel(const float* __restr
             const float4 g = *reinterpret_cast<const float4*>(&s_g[j]);
             // product and subtraction rounded separately (no FMA contraction), as the reference's
             // matmul-then-softmax does, so the arg-max term is exactly exp(0)
-            const float p0 = __expf(__fsub_rn(__fmul_rn(phi, th.x), m)), p1 = __expf(__fsub_rn(__fmul_rn(phi, th.y), m));
-            const float p2 = __expf(__fsub_rn(__fmul_rn(phi, th.z), m)), p3 = __expf(__fsub_rn(__fmul_rn(phi, th.w), m));
+            const float p0 = expf(__fsub_rn(__fmul_rn(phi, th.x), m)), p1 = expf(__fsub_rn(__fmul_rn(phi, th.y), m));
+            const float p2 = expf(__fsub_rn(__fmul_rn(phi, th.z), m)), p3 = expf(__fsub_rn(__fmul_rn(phi, th.w), m));
             den += p0; num += p0 * g.x;
             den += p1; num += p1 * g.y;
             den += p2; num += p2 * g.z;
@@ -221,6 +221,109 @@ __global__ __launch_bounds__(NT) void pose_heads_kernel(const float4* __restrict
 #pragma unroll
         for (int o = 0; o < 6; ++o) out[(size_t)row * 6 + o] = acc[o] + b6[o];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kNN graph (torch_cluster.knn_graph(x, k, batch, loop=False), posenet.py:1043-1050): brute force per graph.
+// One workgroup per query node i: its 4 waves take the candidates j of i's graph in turn and reduce
+// sum_c (x_i[c] - x_j[c])^2 over the 64 lanes (float4 reads); lane 0 of wave 0 then picks the k+1 nearest by
+// (distance, index) -- candidates in index order, strict '<', like torch_cluster's kernel -- and drops the self
+// match (`row != col` mask).  Output: cand[i][0..k] (neighbour ids, -1 = unused), cnt[i].
+// ------------------------------------------------------------------------------------------------
+constexpr int KNN_MAX_GRAPH = 2048;   // nodes per graph (LDS distance row)
+constexpr int KNN_MAX_K = 64;
+
+__global__ __launch_bounds__(NT) void knn_candidates_kernel(const float* __restrict__ x, const int64_t* __restrict__ batch,
+                                                            int n, int d4, int k, int* __restrict__ cand,
+                                                            int* __restrict__ cnt, int* __restrict__ status) {
+    __shared__ float s_dist[KNN_MAX_GRAPH];
+    __shared__ int s_seg[2];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        int lo = 0, hi = n;
+        if (batch) {            // nodes of one graph are contiguous (PyG batching): scan outwards from i
+            const int64_t b = batch[i];
+            lo = i; hi = i + 1;
+            while (lo > 0 && batch[lo - 1] == b) --lo;
+            while (hi < n && batch[hi] == b) ++hi;
+        }
+        s_seg[0] = lo; s_seg[1] = hi;
+    }
+    __syncthreads();
+    const int lo = s_seg[0], hi = s_seg[1], m = hi - lo;
+    if (m > KNN_MAX_GRAPH) {
+        if (tid == 0) { atomicAdd(status, 1); cnt[i] = 0; }
+        return;
+    }
+    const float4* xi = reinterpret_cast<const float4*>(x) + (size_t)i * d4;
+    for (int j = lo + wave; j < hi; j += NT / 64) {
+        const float4* xj = reinterpret_cast<const float4*>(x) + (size_t)j * d4;
+        float acc = 0.f;
+        for (int c = lane; c < d4; c += 64) {
+            const float4 a = xi[c], b = xj[c];
+            const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
+            acc += dx * dx + dy * dy + dz * dz + dw * dw;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) s_dist[j - lo] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // k+1 nearest (self included), insertion into a sorted list; strict '<' keeps the earlier index on ties
+        float bd[KNN_MAX_K + 1];
+        int bi[KNN_MAX_K + 1];
+        const int kk = k + 1;
+        int have = 0;
+        for (int j = 0; j < m; ++j) {
+            const float dj = s_dist[j];
+            if (have < kk || dj < bd[have - 1]) {
+                int p = have < kk ? have : kk - 1;
+                while (p > 0 && dj < bd[p - 1]) { bd[p] = bd[p - 1]; bi[p] = bi[p - 1]; --p; }
+                bd[p] = dj; bi[p] = lo + j;
+                if (have < kk) ++have;
+            }
+        }
+        int c = 0;
+        for (int t = 0; t < have; ++t)
+            if (bi[t] != i) cand[(size_t)i * kk + c++] = bi[t];
+        for (int t = c; t < kk; ++t) cand[(size_t)i * kk + t] = -1;
+        cnt[i] = c;
+    }
+}
+
+// Compaction: edge e of node i goes to offset prefix(cnt)[i] + t; row 0 = neighbour (source), row 1 = i (target).
+// Single workgroup (n up to 2^20), serial prefix per 1024-node chunk.
+__global__ __launch_bounds__(GP_NT) void knn_compact_kernel(const int* __restrict__ cand, const int* __restrict__ cnt,
+                                                            int n, int kk, int e_cap, int64_t* __restrict__ ei,
+                                                            int* __restrict__ total) {
+    __shared__ int s_scan[GP_NT];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += GP_NT) {
+        const int i = base + tid;
+        const int c = (i < n) ? cnt[i] : 0;
+        s_scan[tid] = c;
+        __syncthreads();
+        for (int off = 1; off < GP_NT; off <<= 1) {
+            const int add = (tid >= off) ? s_scan[tid - off] : 0;
+            __syncthreads();
+            s_scan[tid] += add;
+            __syncthreads();
+        }
+        const int start = s_carry + s_scan[tid] - c;
+        if (i < n)
+            for (int t = 0; t < c; ++t) {
+                ei[start + t] = cand[(size_t)i * kk + t];
+                ei[(size_t)e_cap + start + t] = i;
+            }
+        __syncthreads();
+        if (tid == GP_NT - 1) s_carry += s_scan[tid];
+        __syncthreads();
+    }
+    if (tid == 0) *total = s_carry;
 }
 
 inline int capped_grid(long items) {
@@ -294,5 +397,17 @@ extern "C" int rpg_pose_heads_f32(const float* x, const float* w6, const float* 
     hipLaunchKernelGGL(pose_heads_kernel, dim3((r + NT / 64 - 1) / (NT / 64)), dim3(NT), 0, rpg::as_stream(stream),
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(w6), b6, r, d / 4, out);
     RPG_CHECK_LAUNCH("pose_heads");
+    return RPG_OK;
+}
+
+extern "C" int rpg_knn_graph_f32(const float* x, const int64_t* batch, int n, int d, int k, int64_t* edge_index,
+                                 int32_t* cand, int32_t* cnt, int32_t* total, int32_t* status, void* stream) {
+    if (!x || !edge_index || !cand || !cnt || !total || !status || n <= 0 || d <= 0 || (d & 3) || k <= 0 ||
+        k > KNN_MAX_K || n > (1 << 20) || !rpg::aligned16(x))
+        return RPG_ERR_BAD_ARG;
+    hipStream_t s = rpg::as_stream(stream);
+    hipLaunchKernelGGL(knn_candidates_kernel, dim3(n), dim3(NT), 0, s, x, batch, n, d / 4, k, cand, cnt, status);
+    hipLaunchKernelGGL(knn_compact_kernel, dim3(1), dim3(GP_NT), 0, s, cand, cnt, n, k + 1, n * (k + 1), edge_index, total);
+    RPG_CHECK_LAUNCH("knn_graph");
     return RPG_OK;
 }

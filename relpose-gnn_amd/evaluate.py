@@ -1,0 +1,128 @@
+"""Evaluation harness: the caller side of the hot path.
+
+Restates what ``MultiModelTrainer.eval_RP`` does with the model outputs
+(/root/reference/python/niantic/testing/test.py:180-286) so that the HIP module can be evaluated without the reference's
+CLI: pick the reference edge of every graph, turn the predicted relative pose into the query's absolute pose, map the
+log-quaternion back with ``qexp``, un-normalise the translation, accumulate translation / rotation errors, report
+median and mean, and write the ``.npz`` the reference writes.  Differences by design: graphs are evaluated in
+micro-batches (the reference uses batch_size=1, test.py:192; results per graph are independent of the batching), and the
+stream can be sharded over ranks (``relpose_gnn_amd.shard``).  Host-side numpy in float64 like the reference.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .graph import Batch, Data
+
+
+def qexp(v: np.ndarray) -> np.ndarray:
+    """Exponential map R^3 -> unit quaternion (w, x, y, z): [cos|v|, sin|v|/|v| * v]   (pose_utils.py:340-348)."""
+    v = np.asarray(v, dtype=np.float64)
+    n = np.linalg.norm(v)
+    return np.hstack((np.cos(n), np.sinc(n / np.pi) * v))
+
+
+def quaternion_angular_error(q1: np.ndarray, q2: np.ndarray) -> float:
+    """Angle in degrees between two unit quaternions: 2 acos(|<q1,q2>|)   (pose_utils.py:420-431)."""
+    d = abs(float(np.dot(np.asarray(q2, dtype=np.float64), np.asarray(q1, dtype=np.float64))))
+    d = min(1.0, max(-1.0, d))
+    return 2.0 * np.arccos(d) * 180.0 / np.pi
+
+
+def reference_edge(edges: np.ndarray, ref_node: int = 0) -> int:
+    """Index of the ``ref_node``-th edge whose target is node 0, the query (test.py:227-229).  For the stored 8-node
+    fully-connected graphs this is column 28, the edge 1 -> 0."""
+    hits = np.argwhere(np.asarray(edges)[1] == 0)
+    if hits.shape[0] <= ref_node:
+        raise ValueError("graph has no edge into node 0: cannot derive the query pose")
+    return int(hits[ref_node, 0])
+
+
+def query_pose(rel_pose: np.ndarray, target: np.ndarray, edges: np.ndarray, pose_m, pose_s, ref_node: int = 0):
+    """(pred[7], targ[7]) = (t, q) of the query node of ONE graph (test.py:227-251): absolute = ground truth of the
+    reference edge's source node minus the predicted relative pose; rotation through qexp; translation * std + mean."""
+    rel_pose, target = np.asarray(rel_pose, dtype=np.float64), np.asarray(target, dtype=np.float64)
+    ref = reference_edge(edges, ref_node)
+    out = target[np.asarray(edges)[0, ref]] - rel_pose[ref]
+    pred = np.hstack((out[:3] * pose_s + pose_m, qexp(out[3:])))
+    targ = np.hstack((target[0, :3] * pose_s + pose_m, qexp(target[0, 3:])))
+    return pred, targ
+
+
+@dataclass
+class EvalResult:
+    pred_poses: np.ndarray      # [G, 7]
+    targ_poses: np.ndarray      # [G, 7]
+    t_loss: np.ndarray          # [G] metres
+    q_loss: np.ndarray          # [G] degrees
+
+    @property
+    def median_t(self) -> float:
+        return float(np.median(self.t_loss))
+
+    @property
+    def median_q(self) -> float:
+        return float(np.median(self.q_loss))
+
+    def summary(self):
+        """(median_t, mean_t, median_q, mean_q): the tuple eval_RP returns (test.py:286)."""
+        return self.median_t, float(np.mean(self.t_loss)), self.median_q, float(np.mean(self.q_loss))
+
+
+def errors(pred_poses: np.ndarray, targ_poses: np.ndarray) -> EvalResult:
+    t_loss = np.asarray([np.linalg.norm(p - t) for p, t in zip(pred_poses[:, :3], targ_poses[:, :3])])
+    q_loss = np.asarray([quaternion_angular_error(p, t) for p, t in zip(pred_poses[:, 3:], targ_poses[:, 3:])])
+    return EvalResult(pred_poses, targ_poses, t_loss, q_loss)
+
+
+@torch.no_grad()
+def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 32, pose_m=(0.0, 0.0, 0.0),
+                    pose_s=(1.0, 1.0, 1.0), ref_node: int = 0, rank: int = 0, world: int = 1) -> EvalResult:
+    """Run ``model`` over a stream of single-graph ``Data`` objects (x, edge_index, y) and post-process like test.py.
+    With world > 1 every rank evaluates its contiguous block (shard_range) and the [G,7] rows are all-gathered."""
+    from .shard import gather_rows, shard_counts, shard_range
+    pose_m, pose_s = np.asarray(pose_m, dtype=np.float64), np.asarray(pose_s, dtype=np.float64)
+    lo, hi = shard_range(len(graphs), rank, world)
+    preds: List[np.ndarray] = []
+    targs: List[np.ndarray] = []
+    for b0 in range(lo, hi, micro_batch):
+        chunk = [graphs[i] for i in range(b0, min(hi, b0 + micro_batch))]
+        batch = Batch.from_data_list(chunk).to(device)
+        _, rel, edge_index = model(batch)
+        rel = rel.cpu().numpy()
+        edges = edge_index.cpu().numpy()
+        e0 = n0 = 0
+        for g in chunk:
+            n, e = g.num_nodes, g.edge_index.shape[1]
+            if edges.shape[1] != sum(c.edge_index.shape[1] for c in chunk):      # kNN graph returned by the model
+                raise NotImplementedError("per-graph slicing of model-built (kNN) edge lists")
+            p, t = query_pose(rel[e0:e0 + e], g.y.cpu().numpy(), edges[:, e0:e0 + e] - n0, pose_m, pose_s, ref_node)
+            preds.append(p)
+            targs.append(t)
+            e0 += e
+            n0 += n
+    pred = np.stack(preds) if preds else np.zeros((0, 7))
+    targ = np.stack(targs) if targs else np.zeros((0, 7))
+    if world > 1:
+        both = torch.from_numpy(np.concatenate([pred, targ], 1)).to(device)
+        both = gather_rows(both, shard_counts(len(graphs), world)).cpu().numpy()
+        pred, targ = both[:, :7], both[:, 7:]
+    return errors(pred, targ)
+
+
+def save_poses(path, result: EvalResult, rel_paths: Optional[Iterable] = None) -> None:
+    """The .npz of test.py:38-42 (same field names)."""
+    rel_paths = list(rel_paths) if rel_paths is not None else [f"graph_{i:06d}" for i in range(len(result.pred_poses))]
+    assert len(rel_paths) == len(result.pred_poses)
+    np.savez(path, rel_path=rel_paths, abs_t=result.pred_poses[:, :3], abs_q=result.pred_poses[:, 3:],
+             targ_t=result.targ_poses[:, :3], targ_q=result.targ_poses[:, 3:])
+
+
+def load_pose_stats(path):
+    """Cambridge translation mean / std file, two rows of three numbers (test.py:126-130)."""
+    m, s = np.loadtxt(path)
+    return m, s

@@ -93,6 +93,25 @@ def graph_prepare(edge_index: torch.Tensor, n: int) -> Dict[str, torch.Tensor]:
     return {"ends": ends, "rowptr": rowptr, "perm": perm, "status": status}
 
 
+def knn_graph(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """torch_cluster.knn_graph(x, k, batch, loop=False): [2, E] int64, row 0 = neighbour, row 1 = query node.
+    Synchronises once to learn E (E = n*k unless a graph has fewer than k+1 nodes or duplicate rows)."""
+    x = _req(x, "x")
+    n, d = x.shape
+    batch = None if batch is None else _req(batch, "batch", torch.int64)
+    cap = n * (k + 1)
+    ei = torch.empty((2, cap), dtype=torch.int64, device=x.device)
+    cand = torch.empty((n, k + 1), dtype=torch.int32, device=x.device)
+    cnt = torch.empty(n, dtype=torch.int32, device=x.device)
+    meta = torch.zeros(2, dtype=torch.int32, device=x.device)
+    L.check(L.lib().rpg_knn_graph_f32(_p(x), _p(batch), n, d, k, _p(ei), _p(cand), _p(cnt), meta.data_ptr(),
+                                      meta.data_ptr() + 4, _stream()), "knn_graph")
+    total, bad = (int(v) for v in meta.tolist())
+    if bad:
+        raise ValueError("knn_graph: a graph has more than 2048 nodes (unsupported)")
+    return ei[:, :total].contiguous()
+
+
 def edge_concat_gather(x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
     x, ei = _req(x, "x"), _req(edge_index, "edge_index", torch.int64)
     e, d = ei.shape[1], x.shape[1]

@@ -7,8 +7,12 @@ Same constructor keywords, ``forward(data, k=None) -> (abs_pose[N,6], rel_pose[E
 reference's ``simpleConvEdge_upt`` / ``simpleEdgeModel`` / ``AttentionBlock`` children, my_gnn_layer.py:280-291,
 att.py:9-14) only own parameters; the arithmetic is two C calls, ``rpg_resnet_forward_f32`` and ``rpg_gnn_forward_f32``.
 
-Supported configuration = the hot path: ``use_gnn=True, use_AP=True, use_attention=False, knn<=0, k=None``.
-The reference's always-on dropout (``F.dropout`` without ``training=``, posenet.py:1073-1075) is honoured: with
+``use_gnn=True`` is required (the reference's ``use_gnn=False`` branch is unreachable: posenet.py:987-989 touches an
+undefined attribute).  The fast path is ``use_AP=True, use_attention=False, knn<=0, k=None`` (two C calls); the other
+constructor / forward flags of the reference -- ``use_attention`` (posenet.py:1040-1041), ``use_AP=False``
+(:1080-1083), kNN graphs through ``knn>0`` or ``forward(data, k)`` (:1043-1050, ``rpg_knn_graph_f32``), ``L>1``
+(extra ``gnn2..`` parameter sets that the reference creates but never uses, :950-953, :1061-1069) -- run through the
+same kernels with a few more fine-grained calls.  The reference's always-on dropout (``F.dropout`` without ``training=``, posenet.py:1073-1075) is honoured: with
 ``droprate>0`` the node/edge features come back from the GNN call, ``F.dropout`` is applied, and the heads kernel runs on
 the result; parity tests use ``droprate=0``.  Everything runs on the GPU; CPU tensors raise (no fallback).
 """
@@ -64,9 +68,6 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         if not use_gnn:
             raise NotImplementedError("use_gnn=False is outside the accelerated path (and unreachable in the reference: "
                                       "posenet.py:987-989 touches an undefined self.mlp)")
-        if use_attention or not use_AP or L != 1:
-            raise NotImplementedError("only use_attention=False, use_AP=True, L=1 (the R3 evaluation configuration, "
-                                      "testing/test.py:161-167) is built so far")
         if not (feat_dim == node_dim == edge_feat_dim) or feat_dim % 32:
             raise NotImplementedError("feat_dim == node_dim == edge_feat_dim, a multiple of 32, is required")
         self.droprate = droprate
@@ -80,9 +81,12 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         fe_out_planes = self.feature_extractor.fc.in_features
         self.feature_extractor.fc = nn.Linear(fe_out_planes, feat_dim)
         self.proj_edge = nn.Linear(feat_dim * 2, edge_feat_dim)
-        self.gnn1 = simpleConvEdge_upt(node_dim, edge_feat_dim, node_dim)
-        self.fc_xyz = nn.Linear(node_dim, 3)
-        self.fc_wpqr = nn.Linear(node_dim, 3)
+        for layer in range(L):                         # only gnn1 is ever used by forward (posenet.py:1061-1069)
+            setattr(self, f"gnn{layer + 1}", simpleConvEdge_upt(node_dim, edge_feat_dim, node_dim))
+        if self.use_attention:
+            self.att = AttentionBlock(feat_dim)
+        self.fc_xyz = nn.Linear(node_dim if use_AP else node_dim * 2, 3)
+        self.fc_wpqr = nn.Linear(node_dim if use_AP else node_dim * 2, 3)
         self.fc_xyz_R = nn.Linear(node_dim, 3)
         self.fc_wpqr_R = nn.Linear(node_dim, 3)
 
@@ -101,6 +105,7 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         self._enc = EncoderRunner()
         self._gnn_packed: Optional[List[torch.Tensor]] = None
         self._gnn_ptrs = None
+        self._extra: Dict[str, torch.Tensor] = {}
         self._gnn_ws: Dict[Tuple, torch.Tensor] = {}
         self._checked_edges: Dict[Tuple, bool] = {}
 
@@ -109,6 +114,7 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         """Drop the packed device copies of the weights (call after mutating parameters in place)."""
         self._enc.invalidate()
         self._gnn_packed, self._gnn_ptrs = None, None
+        self._extra = {}
         self._gnn_ws.clear()
         self._checked_edges.clear()
 
@@ -128,9 +134,6 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
 
     @torch.no_grad()
     def forward(self, data, k=None):
-        if k is not None or self.knn > 0:
-            raise NotImplementedError("kNN graphs (posenet.py:1043-1050) are a later row of the scope table; "
-                                      "construct with knn=-1 and call forward(data) for the fully-connected path")
         x, edge_index = data.x, data.edge_index
         if not x.is_cuda:
             raise RuntimeError("PoseNetX_R2 (HIP) needs its inputs on the GPU: call data.to(device) first "
@@ -141,12 +144,36 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
 
         if self._gnn_packed is None:
             sd = {kk: v.detach() for kk, v in self.state_dict().items() if not kk.startswith("feature_extractor.")}
+            if not self.use_AP:        # the node heads take pair features: pack them separately, keep slots 18/19 valid
+                self._extra["heads_pair_w"] = torch.cat([sd["fc_xyz.weight"], sd["fc_wpqr.weight"]], 0).float().contiguous()
+                self._extra["heads_pair_b"] = torch.cat([sd["fc_xyz.bias"], sd["fc_wpqr.bias"]], 0).float().contiguous()
+                d = sd["proj_edge.weight"].shape[0]
+                sd["fc_xyz.weight"], sd["fc_wpqr.weight"] = sd["fc_xyz.weight"][:, :d], sd["fc_wpqr.weight"][:, :d]
+            if self.use_attention:
+                self._extra["att_gtp_w"] = torch.cat([sd["att.g.weight"], sd["att.theta.weight"], sd["att.phi.weight"]], 0).float().contiguous()
+                self._extra["att_gtp_b"] = torch.cat([sd["att.g.bias"], sd["att.theta.bias"], sd["att.phi.bias"]], 0).float().contiguous()
+                self._extra["att_w"], self._extra["att_b"] = sd["att.W.weight"].float().contiguous(), sd["att.W.bias"].float().contiguous()
             self._gnn_packed = pack_gnn(sd)
             self._gnn_ptrs = _L.ptr_array([t.data_ptr() for t in self._gnn_packed])
+
+        n, d = feat.shape
+        if self.use_attention:                                                    # posenet.py:1040-1041
+            ex = self._extra
+            y = ops.attention_rows(ops.linear_gather([(feat, None)], ex["att_gtp_w"], ex["att_gtp_b"], n))
+            feat = ops.linear_gather([(y, None)], ex["att_w"], ex["att_b"], n, residual=feat)
+
+        edge_index_knn = None                                                     # posenet.py:1043-1050
+        batch = getattr(data, "batch", None)
+        if k is not None:
+            edge_index_knn = ops.knn_graph(feat, int(k), batch)
+        if self.knn > 0:
+            edge_index = ops.knn_graph(feat, int(self.knn), batch)
+        elif k is not None:
+            edge_index = edge_index_knn
+
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError("edge_index must be an int64 tensor of shape [2, E]")
         ei = edge_index.contiguous()
-        n, d = feat.shape
         e = ei.size(1)
         dev = feat.device
         key = (n, e, d, dev)
@@ -158,7 +185,8 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         rel_pose = torch.empty((e, 6), dtype=torch.float32, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         drop = self.droprate > 0
-        node_f = torch.empty((n, d), dtype=torch.float32, device=dev) if drop else None
+        want_feats = drop or not self.use_AP
+        node_f = torch.empty((n, d), dtype=torch.float32, device=dev) if want_feats else None
         edge_f = torch.empty((e, d), dtype=torch.float32, device=dev) if drop else None
         rc = lib.rpg_gnn_forward_f32(self._gnn_ptrs, len(self._gnn_packed), feat.data_ptr(), ei.data_ptr(), n, e, d,
                                      int(self.gnn_recursion), abs_pose.data_ptr(), rel_pose.data_ptr(),
@@ -177,10 +205,15 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
                 self._checked_edges.clear()
             self._checked_edges[ekey] = True
 
+        t = self._gnn_packed
         if drop:                                                                  # posenet.py:1073-1075 (always on)
             node_f = F.dropout(node_f, p=self.droprate)
             edge_f = F.dropout(edge_f, p=self.droprate)
-            t = self._gnn_packed
-            abs_pose = ops.pose_heads(node_f, t[18], t[19])
             rel_pose = ops.pose_heads(edge_f, t[20], t[21])
-        return abs_pose, rel_pose, edge_index
+            if self.use_AP:
+                abs_pose = ops.pose_heads(node_f, t[18], t[19])
+        if not self.use_AP:                                                       # posenet.py:1080-1083
+            lo, hi = torch.minimum(ei[0], ei[1]), torch.maximum(ei[0], ei[1])     # index plumbing (compute_edge_features)
+            abs_pose = ops.linear_gather([(node_f, lo), (node_f, hi)], self._extra["heads_pair_w"],
+                                         self._extra["heads_pair_b"], e)
+        return abs_pose, rel_pose, (edge_index_knn if k is not None else edge_index)

@@ -97,34 +97,43 @@ def resnet34_param_shapes(prefix: str = "feature_extractor.", feat_dim: int = 20
 
 
 def posenet_r2_param_shapes(feat_dim: int = 2048, edge_feat_dim: int = 2048, node_dim: int = 2048,
-                            planes=RESNET34_PLANES, blocks=RESNET34_BLOCKS) -> "OrderedDict[str, Tuple[int, ...]]":
-    """Full PoseNetX_R2 (use_gnn=True, use_AP=True, L=1) state dict inventory, in the order the
-    reference module registers its children (posenet.py:941-975)."""
+                            planes=RESNET34_PLANES, blocks=RESNET34_BLOCKS, use_attention: bool = False,
+                            use_AP: bool = True, L: int = 1) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Full PoseNetX_R2 (use_gnn=True) state dict inventory, in the order the reference module registers its
+    children (posenet.py:941-975): encoder, proj_edge, gnn1..gnnL, [att], fc_xyz, fc_wpqr, fc_xyz_R, fc_wpqr_R."""
     assert feat_dim == node_dim, "the reference feeds encoder features straight into gnn1 (posenet.py:1063)"
     sd = resnet34_param_shapes("feature_extractor.", feat_dim, planes, blocks)
     D, De = node_dim, edge_feat_dim
     sd["proj_edge.weight"] = (De, 2 * feat_dim)
     sd["proj_edge.bias"] = (De,)
     # simpleConvEdge_upt(node_dim, edge_feat_dim, node_dim): mlp, mlp_updating, edge_model, att
-    sd["gnn1.mlp.0.weight"] = (D, D + De)
-    sd["gnn1.mlp.0.bias"] = (D,)
-    sd["gnn1.mlp.2.weight"] = (D, D)
-    sd["gnn1.mlp.2.bias"] = (D,)
-    sd["gnn1.mlp_updating.0.weight"] = (D, 2 * D)
-    sd["gnn1.mlp_updating.0.bias"] = (D,)
-    sd["gnn1.mlp_updating.2.weight"] = (D, D)
-    sd["gnn1.mlp_updating.2.bias"] = (D,)
-    sd["gnn1.edge_model.edge_mlp.0.weight"] = (De, 2 * D + De)
-    sd["gnn1.edge_model.edge_mlp.0.bias"] = (De,)
-    sd["gnn1.edge_model.edge_mlp.2.weight"] = (De, De)
-    sd["gnn1.edge_model.edge_mlp.2.bias"] = (De,)
-    for n in ("g", "theta", "phi"):
-        sd[f"gnn1.att.{n}.weight"] = (D // 8, D)
-        sd[f"gnn1.att.{n}.bias"] = (D // 8,)
-    sd["gnn1.att.W.weight"] = (D, D // 8)
-    sd["gnn1.att.W.bias"] = (D,)
+    for li in range(1, L + 1):
+        g = f"gnn{li}."
+        sd[g + "mlp.0.weight"] = (D, D + De)
+        sd[g + "mlp.0.bias"] = (D,)
+        sd[g + "mlp.2.weight"] = (D, D)
+        sd[g + "mlp.2.bias"] = (D,)
+        sd[g + "mlp_updating.0.weight"] = (D, 2 * D)
+        sd[g + "mlp_updating.0.bias"] = (D,)
+        sd[g + "mlp_updating.2.weight"] = (D, D)
+        sd[g + "mlp_updating.2.bias"] = (D,)
+        sd[g + "edge_model.edge_mlp.0.weight"] = (De, 2 * D + De)
+        sd[g + "edge_model.edge_mlp.0.bias"] = (De,)
+        sd[g + "edge_model.edge_mlp.2.weight"] = (De, De)
+        sd[g + "edge_model.edge_mlp.2.bias"] = (De,)
+        for n in ("g", "theta", "phi"):
+            sd[f"{g}att.{n}.weight"] = (D // 8, D)
+            sd[f"{g}att.{n}.bias"] = (D // 8,)
+        sd[g + "att.W.weight"] = (D, D // 8)
+        sd[g + "att.W.bias"] = (D,)
+    if use_attention:                                   # self.att = AttentionBlock(feat_dim), posenet.py:961-962
+        for n in ("g", "theta", "phi"):
+            sd[f"att.{n}.weight"] = (feat_dim // 8, feat_dim)
+            sd[f"att.{n}.bias"] = (feat_dim // 8,)
+        sd["att.W.weight"] = (feat_dim, feat_dim // 8)
+        sd["att.W.bias"] = (feat_dim,)
     for n in ("fc_xyz", "fc_wpqr"):
-        sd[n + ".weight"] = (3, D)
+        sd[n + ".weight"] = (3, D if use_AP else 2 * D)
         sd[n + ".bias"] = (3,)
     for n in ("fc_xyz_R", "fc_wpqr_R"):
         sd[n + ".weight"] = (3, De)

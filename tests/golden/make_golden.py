@@ -66,8 +66,13 @@ class MessagePassing(torch.nn.Module):
         return aggr_out
 
 
-def _knn_graph(*a, **k):
-    raise RuntimeError("knn_graph is not on the fully-connected hot path")
+def _knn_graph(x, k, batch=None, loop=False, **kw):
+    """torch_cluster is not installed: the reference's kNN call sites (posenet.py:1044-1050) get the oracle's restatement
+    of the published algorithm.  This pins the reference's control flow around the kNN graph (which edge list feeds the
+    GNN, which one is returned), NOT the neighbour search itself."""
+    from oracle import posenet_ref as O
+    assert not loop
+    return O.knn_graph(x, k, batch)
 
 
 def install_stubs():
@@ -216,6 +221,47 @@ def main():
     assert rel_err(o_abs, r_abs) < 1e-5 and rel_err(o_rel, r_rel) < 1e-5
     np.savez(os.path.join(HERE, "g5_full_r3_224.npz"), abs=r_abs.numpy(), rel=r_rel.numpy(),
              **{"l2_" + k: np.float64(v.double().norm().item()) for k, v in stages.items()})
+
+    # ---- G7: constructor flags use_attention=True, use_AP=False, L=2 (extra unused gnn2 weights) ----------------
+    fe = ResNetCPU(blocks=small_blocks, planes=small_planes)
+    m7 = PoseNetX_R2(fe, droprate=0.0, pretrained=False, feat_dim=64, edge_feat_dim=64, node_dim=64, input_img_height=32,
+                     use_gnn=True, use_attention=True, knn=-1, use_AP=False, gnn_recursion=2, L=2)
+    shapes7 = S.posenet_r2_param_shapes(64, 64, 64, small_planes, small_blocks, use_attention=True, use_AP=False, L=2)
+    assert list(m7.state_dict().keys()) == list(shapes7.keys())
+    assert all(tuple(v.shape) == tuple(shapes7[k]) for k, v in m7.state_dict().items())
+    sd7 = S.synth_state_dict(shapes7, seed=7)
+    m7.load_state_dict(sd7)
+    m7.eval()
+    x = S.synth_images(16, 32, 40, seed=3)
+    ei = O.batch_edge_index(8, 2)
+    o_abs, o_rel, _ = O.posenet_forward(sd7, x, ei, 32, 2, use_attention=True, use_AP=False)
+    with torch.no_grad():
+        r_abs, r_rel, _ = m7(types.SimpleNamespace(x=x, edge_index=ei, edge_attr=None, batch=None))
+    print("g7 oracle vs reference:", rel_err(o_abs, r_abs), rel_err(o_rel, r_rel), tuple(r_abs.shape))
+    assert r_abs.shape == (112, 6) and rel_err(o_abs, r_abs) < 2e-6 and rel_err(o_rel, r_rel) < 2e-6
+    np.savez(os.path.join(HERE, "g7_flags_att_noAP_L2.npz"), abs=r_abs.numpy(), rel=r_rel.numpy())
+
+    # ---- G8: kNN control flow (knn=3 in the constructor; forward(data, k=2)) with the stand-in neighbour search -----
+    x = S.synth_images(16, 32, 40, seed=9)
+    ei = O.batch_edge_index(8, 2)
+    bvec = torch.arange(2).repeat_interleave(8)
+    m64.knn = 3
+    with torch.no_grad():
+        a_c, r_c, e_c = m64(types.SimpleNamespace(x=x, edge_index=ei, edge_attr=None, batch=bvec))
+        a_k, r_k, e_k = m64(types.SimpleNamespace(x=x, edge_index=ei, edge_attr=None, batch=bvec), k=2)
+    m64.knn = -1
+    with torch.no_grad():
+        a_f, r_f, e_f = m64(types.SimpleNamespace(x=x, edge_index=ei, edge_attr=None, batch=bvec), k=2)
+    o1 = O.posenet_forward(sd64, x, ei, 32, 2, knn=3, batch=bvec)
+    o2 = O.posenet_forward(sd64, x, ei, 32, 2, knn=3, k=2, batch=bvec)
+    o3 = O.posenet_forward(sd64, x, ei, 32, 2, k=2, batch=bvec)
+    for (ra, rr, re), (oa, orr, oe) in (((a_c, r_c, e_c), o1), ((a_k, r_k, e_k), o2), ((a_f, r_f, e_f), o3)):
+        assert torch.equal(re, oe) and rel_err(oa, ra) < 2e-6 and rel_err(orr, rr) < 2e-6
+    assert e_c.shape == (2, 48) and e_k.shape == (2, 32) and r_k.shape == (48, 6) and r_f.shape == (32, 6)
+    print("g8 kNN control flow: oracle == reference (with stand-in knn_graph)")
+    np.savez(os.path.join(HERE, "g8_knn_flow.npz"), abs_ctor=a_c.numpy(), rel_ctor=r_c.numpy(), ei_ctor=e_c.numpy(),
+             abs_both=a_k.numpy(), rel_both=r_k.numpy(), ei_both=e_k.numpy(),
+             abs_fwd=a_f.numpy(), rel_fwd=r_f.numpy(), ei_fwd=e_f.numpy())
 
     # ---- G6: caller-side pose utilities ------------------------------------------------------
     rng = np.random.RandomState(7)

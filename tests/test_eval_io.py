@@ -1,0 +1,120 @@
+"""Host-side rows next to the hot path: evaluation post-processing and the PyG-free readers."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import posenet_ref as O
+from relpose_gnn_amd import evaluate as E
+from relpose_gnn_amd.graph import Data, fc_edge_index
+
+
+def test_pose_utils_against_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g6_pose_utils.npz"))       # written by the reference's pose_utils
+    for i in range(6):
+        assert np.allclose(E.qexp(g["v"][i]), g["q"][i], atol=1e-12)
+        assert np.isclose(E.quaternion_angular_error(g["q"][i], g["q"][(i + 1) % 6]), g["ang"][i], atol=1e-9)
+
+
+def test_query_pose_rule():
+    rng = np.random.RandomState(0)
+    ei = fc_edge_index(8).numpy()
+    rel, y = rng.randn(56, 6) * 0.1, rng.randn(8, 6) * 0.3
+    assert E.reference_edge(ei) == 28 and ei[:, 28].tolist() == [1, 0]
+    m, s = np.array([1.0, 2.0, 3.0]), np.array([2.0, 2.0, 0.5])
+    pred, targ = E.query_pose(rel, y, ei, m, s)
+    raw = O.query_pose_from_relative(rel, y, ei)                       # oracle statement of test.py:227-232
+    assert np.allclose(pred[:3], raw[:3] * s + m) and np.allclose(pred[3:], O.qexp(raw[3:]))
+    assert np.allclose(targ[:3], y[0, :3] * s + m) and np.allclose(targ[3:], O.qexp(y[0, 3:]))
+    res = E.errors(np.stack([pred, targ]), np.stack([targ, targ]))
+    assert res.t_loss[1] == 0 and res.q_loss[1] < 1e-5 and res.t_loss[0] > 0
+    with pytest.raises(ValueError):
+        E.reference_edge(np.array([[0, 1], [1, 2]]))
+
+
+class _FakeModel:
+    """rel = y[dst] - y[src] + 0.01: lets the harness be checked on CPU without the HIP module."""
+
+    def __call__(self, batch):
+        ei = batch.edge_index
+        return None, batch.y[ei[1]] - batch.y[ei[0]] + 0.01, ei
+
+
+def test_evaluate_stream_and_npz(tmp_path):
+    rng = np.random.RandomState(1)
+    graphs = []
+    for _ in range(5):
+        y = torch.from_numpy(rng.randn(8, 6) * 0.2).float()
+        graphs.append(Data(x=torch.zeros(8, 12), edge_index=fc_edge_index(8), y=y))
+    res = E.evaluate_stream(_FakeModel(), graphs, "cpu", micro_batch=2)
+    assert res.pred_poses.shape == (5, 7)
+    for i, g in enumerate(graphs):                                      # pred = y[1] - (y[0]-y[1]+0.01)
+        y = g.y.numpy().astype(np.float64)
+        exp = y[1] - (y[0] - y[1] + 0.01)
+        assert np.allclose(res.pred_poses[i, :3], exp[:3], atol=1e-6)
+        assert np.allclose(res.pred_poses[i, 3:], E.qexp(exp[3:]), atol=1e-6)
+    assert len(res.summary()) == 4 and res.median_t == float(np.median(res.t_loss))
+    E.save_poses(tmp_path / "out.npz", res)
+    z = np.load(tmp_path / "out.npz")
+    assert set(z.files) == {"rel_path", "abs_t", "abs_q", "targ_t", "targ_q"} and z["abs_q"].shape == (5, 4)
+
+
+def _fake_pyg(layout):
+    """Install throw-away modules shaped like PyG so that torch.save writes pickles with torch_geometric class paths."""
+    mods = {n: types.ModuleType(n) for n in ("torch_geometric", "torch_geometric.data", "torch_geometric.data.data",
+                                             "torch_geometric.data.storage")}
+
+    class GlobalStorage:
+        def __init__(self):
+            self._mapping = {}
+    GlobalStorage.__module__ = "torch_geometric.data.storage"
+
+    class PygData:
+        def __init__(self, **kw):
+            if layout == "v2":
+                self._store = GlobalStorage()
+                self._store._mapping.update(kw)
+            else:
+                self.__dict__.update(kw)
+    PygData.__module__, PygData.__qualname__, PygData.__name__ = "torch_geometric.data.data", "Data", "Data"
+    GlobalStorage.__qualname__ = "GlobalStorage"
+    mods["torch_geometric.data.data"].Data = PygData
+    mods["torch_geometric.data.storage"].GlobalStorage = GlobalStorage
+    return mods, PygData
+
+
+@pytest.mark.parametrize("layout", ["v1", "v2"])
+def test_graph_reader_without_pyg(tmp_path, layout):
+    from relpose_gnn_amd import io as rio
+    mods, PygData = _fake_pyg(layout)
+    x, ei = torch.randn(8, 30), fc_edge_index(8)
+    y = torch.randn(8, 6)
+    sample = PygData(x=x, edge_index=ei, y=y, edge_attr=y[ei[1]] - y[ei[0]])
+    os.makedirs(tmp_path / "processed")
+    sys.modules.update(mods)
+    try:
+        for i in (0, 1, 10, 2):
+            torch.save(sample, tmp_path / "processed" / f"data_{i}.pt")
+    finally:
+        for n in mods:
+            sys.modules.pop(n, None)
+    files = rio.processed_files(str(tmp_path))
+    assert [os.path.basename(f) for f in files] == ["data_0.pt", "data_1.pt", "data_2.pt", "data_10.pt"]
+    d = rio.load_graph(files[3])
+    assert torch.equal(d.x, x) and torch.equal(d.edge_index, ei) and torch.equal(d.y, y) and d.edge_attr.shape == (56, 6)
+    assert "torch_geometric" not in sys.modules
+    bad = tmp_path / "bad.pt"
+    torch.save({"z": 1}, bad)
+    with pytest.raises(ValueError):
+        rio.load_graph(str(bad))
+
+
+def test_checkpoint_reader(tmp_path):
+    from relpose_gnn_amd import io as rio
+    sd = {"proj_edge.weight": torch.randn(4, 8)}
+    torch.save({"epoch": 199, "model_state_dict": sd, "optim_state_dict": {}, "criterion_state_dict": {}}, tmp_path / "epoch_199.pth.tar")
+    out = rio.load_checkpoint_state_dict(str(tmp_path / "epoch_199.pth.tar"))
+    assert torch.equal(out["proj_edge.weight"], sd["proj_edge.weight"])

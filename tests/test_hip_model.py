@@ -155,11 +155,87 @@ def test_batch_independence_full_width(dev):
     """Size-independent property at a BASELINE-sized batch (32 graphs x 8 nodes, D=2048, small images to bound the
     oracle-free check): a graph's poses do not depend on which other graphs share the batch."""
     import relpose_gnn_amd.synth as S
-    m, _ = _build(2048, 64, (64, 128, 256, 512), (3, 4, 6, 3), dev)
+    from oracle import posenet_ref as O
+    m, sd = _build(2048, 64, (64, 128, 256, 512), (3, 4, 6, 3), dev)
     x = S.synth_images(8 * 32, 64, 64, seed=8)
     a, r, _ = m(_data(x, 8, dev))
     a1, r1, _ = m(_data(x[8 * 5: 8 * 6], 8, dev))
+    oa, orr, _ = O.posenet_forward(sd, x[8 * 5: 8 * 6], O.fc_edge_index(8), 64, 2)
+    _report("R3_D2048_64px_graph5_in_batch32_vs_live_oracle", rel_err(a[40:48].cpu(), oa), rel_err(r[56 * 5: 56 * 6].cpu(), orr))
+    _report("R3_D2048_64px_graph5_alone_vs_live_oracle", rel_err(a1.cpu(), oa), rel_err(r1.cpu(), orr))
+    assert rel_err(a[40:48].cpu(), oa) < TOL and rel_err(a1.cpu(), oa) < TOL
     # not bit-equal: the stream-K split of the K range (hence the fp32 summation order) depends on the batch size
     ea, er = rel_err(a[40:48].cpu(), a1.cpu()), rel_err(r[56 * 5: 56 * 6].cpu(), r1.cpu())
     _report("batch_independence_32_vs_1_graphs", ea, er)
     assert ea < TOL and er < TOL, (ea, er)
+
+
+def test_constructor_flags_vs_golden_g7(dev, golden_dir):
+    """use_attention=True, use_AP=False, L=2 (posenet.py:961-972,1040-1041,1080-1083)."""
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd.posenet import PoseNetX_R2
+    from relpose_gnn_amd.resnet import ResNet
+    planes, blocks = (8, 16, 32, 64), (1, 1, 1, 1)
+    m = PoseNetX_R2(ResNet(blocks, planes), droprate=0.0, pretrained=False, feat_dim=64, edge_feat_dim=64, node_dim=64,
+                    input_img_height=32, use_gnn=True, use_attention=True, knn=-1, use_AP=False, gnn_recursion=2, L=2)
+    m.load_state_dict(S.synth_state_dict(S.posenet_r2_param_shapes(64, 64, 64, planes, blocks, use_attention=True,
+                                                                    use_AP=False, L=2), seed=7))
+    m = m.to(dev).eval()
+    a, r, _ = m(_data(S.synth_images(16, 32, 40, seed=3), 8, dev))
+    g = np.load(os.path.join(golden_dir, "g7_flags_att_noAP_L2.npz"))
+    assert a.shape == (112, 6)
+    ea, er = rel_err(a.cpu(), g["abs"]), rel_err(r.cpu(), g["rel"])
+    _report("g7_flags_attention_noAP_L2_vs_reference_golden", ea, er)
+    assert ea < TOL and er < TOL
+
+
+def test_knn_paths_vs_golden_g8(dev, golden_dir):
+    """knn>0 in the constructor, forward(data, k), and both (posenet.py:1043-1050, 1088-1091)."""
+    import relpose_gnn_amd.synth as S
+    m, _ = _build(64, 32, (8, 16, 32, 64), (1, 1, 1, 1), dev)
+    g = np.load(os.path.join(golden_dir, "g8_knn_flow.npz"))
+    d = _data(S.synth_images(16, 32, 40, seed=9), 8, dev)
+    for tag, knn, k in (("ctor", 3, None), ("both", 3, 2), ("fwd", -1, 2)):
+        m.knn = knn
+        a, r, e = m(d, k=k)
+        assert np.array_equal(e.cpu().numpy(), g["ei_" + tag]), tag
+        ea, er = rel_err(a.cpu(), g["abs_" + tag]), rel_err(r.cpu(), g["rel_" + tag])
+        _report(f"g8_knn_{tag}_vs_reference_golden", ea, er)
+        assert ea < TOL and er < TOL
+    m.knn = -1
+
+
+def test_eval_shape_256x341_vs_oracle(dev):
+    """BASELINE.json configs[3] shape: the 7-Scenes evaluation images are 256x341 (odd width, ragged tiles everywhere),
+    8-node FC graph, R3 dims; one graph through the live oracle."""
+    import relpose_gnn_amd.synth as S
+    from oracle import posenet_ref as O
+    m, sd = _build(2048, 256, (64, 128, 256, 512), (3, 4, 6, 3), dev)
+    x = S.synth_images(8, 256, 341, seed=12)
+    d = _data(x, 8, dev)
+    a, r, _ = m(d)
+    oa, orr, _ = O.posenet_forward(sd, x, d.edge_index.cpu(), 256, 2)
+    ea, er = rel_err(a.cpu(), oa), rel_err(r.cpu(), orr)
+    _report("R3_D2048_256x341_8node_vs_live_oracle", ea, er)
+    assert ea < TOL and er < TOL, (ea, er)
+
+
+def test_eval_harness_end_to_end(dev):
+    """evaluate_stream on the HIP module == oracle forward + oracle post-processing (test.py:213-276 semantics)."""
+    import relpose_gnn_amd.synth as S
+    from oracle import posenet_ref as O
+    from relpose_gnn_amd import evaluate as E
+    from relpose_gnn_amd.graph import Data, fc_edge_index
+    m, sd = _build(64, 32, (8, 16, 32, 64), (1, 1, 1, 1), dev)
+    graphs, ref_pred = [], []
+    pm, ps = np.array([0.5, -1.0, 2.0]), np.array([2.0, 3.0, 0.5])
+    for i in range(7):
+        x = S.synth_images(8, 32, 40, seed=100 + i)
+        y = S.hash_normal(f"eval.y{i}", (8, 6), 0.3)
+        graphs.append(Data(x=x, edge_index=fc_edge_index(8), y=y))
+        _, rel, _ = O.posenet_forward(sd, x, fc_edge_index(8), 32, 2)
+        raw = O.query_pose_from_relative(rel.numpy().astype(np.float64), y.numpy().astype(np.float64), fc_edge_index(8).numpy())
+        ref_pred.append(np.hstack((raw[:3] * ps + pm, O.qexp(raw[3:]))))
+    res = E.evaluate_stream(m, graphs, dev, micro_batch=3, pose_m=pm, pose_s=ps)
+    assert np.allclose(res.pred_poses, np.stack(ref_pred), atol=2e-4, rtol=1e-4)
+    assert res.t_loss.shape == (7,) and np.isfinite(res.summary()).all()

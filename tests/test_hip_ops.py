@@ -263,3 +263,18 @@ def test_tile_engine_variants(dev, bk, epi, tile, streamk):
         ops.set_tuning(ops.TUNE_EPILOGUE, 1)
         ops.set_tuning(ops.TUNE_TILE, -1)
         ops.set_tuning(ops.TUNE_STREAMK, 1)
+
+
+@pytest.mark.parametrize("sizes,k,d", [((8, 8, 8), 4, 2048), ((8, 9, 3, 1), 4, 64), ((40,), 7, 128)])
+def test_knn_graph(dev, sizes, k, d):
+    """rpg_knn_graph_f32 vs the oracle's restatement of torch_cluster.knn_graph (ragged graphs, graphs smaller than k+1)."""
+    from relpose_gnn_amd import ops
+    from oracle.posenet_ref import knn_graph
+    n = sum(sizes)
+    x = _rand(n, d, seed=31)
+    b = torch.cat([torch.full((s,), i, dtype=torch.int64) for i, s in enumerate(sizes)])
+    ref = knn_graph(x, k, b)
+    got = ops.knn_graph(x.to(dev), k, b.to(dev)).cpu()
+    assert torch.equal(got, ref)
+    if len(sizes) == 1:
+        assert torch.equal(ops.knn_graph(x.to(dev), k, None).cpu(), ref)

@@ -47,11 +47,13 @@ def test_state_dict_contract_matches_reference_inventory():
     m.load_state_dict(S.synth_state_dict(shapes, seed=3))
     with pytest.raises(RuntimeError):                    # no CPU fallback
         m(fc_batch(torch.zeros(8, 3 * 224 * 224), 8))
-    for kw in (dict(use_gnn=False), dict(use_gnn=True, use_attention=True), dict(use_gnn=True, use_AP=False)):
-        with pytest.raises(NotImplementedError):
-            PoseNetX_R2(resnet34(), **kw)
     with pytest.raises(NotImplementedError):
-        PoseNetX_R2(resnet34(), use_gnn=True, knn=4)(fc_batch(torch.zeros(8, 12), 8))
+        PoseNetX_R2(resnet34(), use_gnn=False)
+    # the other constructor flags keep the reference's state-dict inventory (checked against it in make_golden.py)
+    m2 = PoseNetX_R2(resnet34(), feat_dim=64, edge_feat_dim=64, node_dim=64, use_gnn=True, use_attention=True,
+                     use_AP=False, L=2)
+    assert list(m2.state_dict().keys()) == list(S.posenet_r2_param_shapes(64, 64, 64, use_attention=True, use_AP=False, L=2).keys())
+    assert m2.fc_xyz.in_features == 128
     assert torch.equal(m.compute_RP(torch.arange(12.).view(4, 3), torch.tensor([[0, 3], [1, 1]])),
                        torch.tensor([[-3., -3., -3.], [6., 6., 6.]]))
 

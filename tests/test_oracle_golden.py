@@ -96,3 +96,40 @@ def test_oracle_pieces_properties():
     assert float(O.scatter_mean(msg[:3], torch.tensor([0, 0, 2]), 4)[[1, 3]].abs().max()) == 0.0
     pose = O.query_pose_from_relative(np.arange(56 * 6.0).reshape(56, 6), np.ones((8, 6)), ei.numpy())
     assert np.allclose(pose, 1.0 - np.arange(28 * 6, 29 * 6))
+
+
+def test_g7_constructor_flags(golden_dir):
+    """use_attention=True, use_AP=False, L=2: oracle vs the reference's outputs."""
+    g = np.load(os.path.join(golden_dir, "g7_flags_att_noAP_L2.npz"))
+    shapes = S.posenet_r2_param_shapes(64, 64, 64, use_attention=True, use_AP=False, L=2, **SMALL)
+    sd = S.synth_state_dict(shapes, seed=7)
+    x = S.synth_images(16, 32, 40, seed=3)
+    a, r, _ = O.posenet_forward(sd, x, O.batch_edge_index(8, 2), 32, 2, use_attention=True, use_AP=False)
+    assert a.shape == (112, 6) and rel_err(a, g["abs"]) < 1e-6 and rel_err(r, g["rel"]) < 1e-6
+
+
+def test_g8_knn_control_flow(golden_dir):
+    """Which edge list feeds the GNN and which one is returned for knn>0 / forward(k) (posenet.py:1043-1050,1088-1091).
+    The neighbour search itself is the oracle's restatement on both sides (torch_cluster absent: parity unpinned)."""
+    g = np.load(os.path.join(golden_dir, "g8_knn_flow.npz"))
+    sd = S.synth_state_dict(S.posenet_r2_param_shapes(64, 64, 64, **SMALL), seed=1)
+    x = S.synth_images(16, 32, 40, seed=9)
+    ei = O.batch_edge_index(8, 2)
+    b = torch.arange(2).repeat_interleave(8)
+    for tag, kw in (("ctor", dict(knn=3)), ("both", dict(knn=3, k=2)), ("fwd", dict(k=2))):
+        a, r, e = O.posenet_forward(sd, x, ei, 32, 2, batch=b, **kw)
+        assert np.array_equal(e.numpy(), g["ei_" + tag])
+        assert rel_err(a, g["abs_" + tag]) < 1e-6 and rel_err(r, g["rel_" + tag]) < 1e-6
+
+
+def test_knn_graph_properties():
+    x = S.hash_normal("knn.x", (20, 16))
+    b = torch.tensor([0] * 8 + [1] * 9 + [2] * 3)
+    e = O.knn_graph(x, 4, b)
+    assert e.shape[1] == 8 * 4 + 9 * 4 + 3 * 2                  # a 3-node graph only has 2 other nodes
+    assert bool((b[e[0]] == b[e[1]]).all()) and bool((e[0] != e[1]).all())
+    assert torch.equal(e[1], torch.sort(e[1], stable=True).values)          # grouped by target in node order
+    d = ((x[e[0]] - x[e[1]]) ** 2).sum(1)
+    for v in range(20):
+        dv = d[e[1] == v]
+        assert bool((dv[1:] >= dv[:-1]).all())                              # nearest first
