@@ -57,6 +57,15 @@ int rpg_conv2d_bn_act_nhwc_f32(const float* x, const float* w_ohwi, const float*
                                const float* residual, float* y, int n, int h, int w, int cin, int cout,
                                int kh, int kw, int stride, int pad, int relu, void* stream);
 
+/* The same op for the 3x3 / stride 1 / pad 1 case as a 1-D Winograd F(4,3) along the width: half the f32 MFMA work.
+ *   u  [6][cout][3][cin]   transformed weights from rpg_wino43_transform_weights_f32 (once per weight load)
+ *   cin % 4 == 0, cout % 4 == 0; x [n][h][w][cin] -> y [n][h][w][cout]; other arguments as above.            */
+int rpg_wino43_transform_weights_f32(const float* w_ohwi /* [cout][3][3][cin] */, float* u, int cout, int cin,
+                                     void* stream);
+int rpg_conv3x3_wino43_bn_act_nhwc_f32(const float* x, const float* u, const float* scale, const float* shift,
+                                       const float* residual, float* y, int n, int h, int w, int cin, int cout,
+                                       int relu, void* stream);
+
 /* nn.MaxPool2d(3, stride 2, padding 1), NHWC, c % 4 == 0. */
 int rpg_maxpool3x3s2_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, void* stream);
 
@@ -66,7 +75,9 @@ int rpg_global_avgpool_nhwc_f32(const float* x, float* y, int n, int hw, int c, 
 /* Whole encoder: torchvision-0.9.1 ResNet (BasicBlock) forward incl. the replaced fc
  * (posenet.py:942-945, :1037).  `tensors` is a HOST array of device pointers laid out as
  * documented in relpose-gnn_amd/params.py (stem, then per block conv1/conv2/(downsample), each
- * as {w_ohwi, scale, shift}, then fc weight [feat][512] and bias).  `blocks[4]`/`planes[4]` HOST.
+ * as {w_ohwi, scale, shift, u_wino43}, then fc weight [feat][512] and bias).  u_wino43 may be NULL
+ * (always for the stem, strided and 1x1 convolutions): that convolution then takes the direct
+ * implicit-GEMM kernel.  `blocks[4]`/`planes[4]` HOST.
  * x_nchw [n][3][h][w] -> feat [n][feat_dim].                                                     */
 size_t rpg_resnet_workspace_bytes(int n, int h, int w, const int* planes);
 int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors, const int* blocks, const int* planes,
@@ -165,6 +176,7 @@ int rpg_timing_read(double* ms, long long* launches, double* work);
 #define RPG_TUNE_BK 1
 #define RPG_TUNE_EPILOGUE 2
 #define RPG_TUNE_STREAMK 3
+#define RPG_TUNE_WINOGRAD 4       /* 1: use u_wino43 where given (default) | 0: always the direct kernel */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

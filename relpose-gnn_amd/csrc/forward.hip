@@ -65,17 +65,17 @@ extern "C" int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors
                                       void* workspace, size_t workspace_bytes, void* stream) {
     if (!tensors || !blocks || !planes || !x_nchw || !feat || !workspace || n <= 0 || h <= 0 || w <= 0 || feat_dim <= 0)
         return RPG_ERR_BAD_ARG;
-    // tensor count: stem 3 + per block 6 (+3 with downsample) + fc 2
-    int expect = 3 + 2, cin = planes[0];
+    // tensor count: stem 4 + per block 8 (+4 with downsample) + fc 2; every 4th entry (u_wino43) may be NULL
+    int expect = 4 + 2, cin = planes[0];
     for (int l = 0; l < 4; ++l)
         for (int b = 0; b < blocks[l]; ++b) {
             const int stride = (l > 0 && b == 0) ? 2 : 1;
-            expect += 6 + ((stride != 1 || cin != planes[l]) ? 3 : 0);
+            expect += 8 + ((stride != 1 || cin != planes[l]) ? 4 : 0);
             cin = planes[l];
         }
     if (n_tensors != expect) return RPG_ERR_BAD_ARG;
     for (int i = 0; i < n_tensors; ++i)
-        if (!tensors[i]) return RPG_ERR_BAD_ARG;
+        if (!tensors[i] && !((i & 3) == 3 && i < n_tensors - 2)) return RPG_ERR_BAD_ARG;
     const ResnetPlan p = plan_resnet(n, h, w, planes);
     if (workspace_bytes < p.total_bytes) return RPG_ERR_WORKSPACE;
     hipStream_t s = rpg::as_stream(stream);
@@ -94,7 +94,7 @@ extern "C" int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors
     if ((rc = rpg::launch_conv(in4, tensors[ti], tensors[ti + 1], tensors[ti + 2], nullptr, stem, n, h, w, 4,
                                planes[0], 7, 7, 2, 3, 1, s, 3)) != RPG_OK)
         return rc;
-    ti += 3;
+    ti += 4;
     if ((rc = rpg_maxpool3x3s2_nhwc_f32(stem, buf[0], n, p.h1, p.w1, planes[0], stream)) != RPG_OK) return rc;
 
     int cur = 0, hh = p.h2, ww = p.w2;
@@ -110,21 +110,29 @@ extern "C" int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors
             float* Y = buf[(cur + 2) & 3];
             float* D = buf[(cur + 3) & 3];
             // conv1 3x3/stride + BN + ReLU
-            if ((rc = rpg::launch_conv(X, tensors[ti], tensors[ti + 1], tensors[ti + 2], nullptr, T, n, hh, ww, cin, c, 3,
-                                       3, stride, 1, 1, s)) != RPG_OK)
-                return rc;
+            if (stride == 1 && tensors[ti + 3] && rpg::wino_enabled())
+                rc = rpg::launch_conv_wino(X, tensors[ti + 3], tensors[ti + 1], tensors[ti + 2], nullptr, T, n, hh, ww, cin,
+                                           c, 1, s);
+            else
+                rc = rpg::launch_conv(X, tensors[ti], tensors[ti + 1], tensors[ti + 2], nullptr, T, n, hh, ww, cin, c, 3, 3,
+                                      stride, 1, 1, s);
+            if (rc != RPG_OK) return rc;
             const float* identity = X;
             if (ds) {   // downsample: conv1x1/stride + BN (no activation)
-                if ((rc = rpg::launch_conv(X, tensors[ti + 6], tensors[ti + 7], tensors[ti + 8], nullptr, D, n, hh, ww,
+                if ((rc = rpg::launch_conv(X, tensors[ti + 8], tensors[ti + 9], tensors[ti + 10], nullptr, D, n, hh, ww,
                                            cin, c, 1, 1, stride, 0, 0, s)) != RPG_OK)
                     return rc;
                 identity = D;
             }
             // conv2 3x3/1 + BN + identity + ReLU
-            if ((rc = rpg::launch_conv(T, tensors[ti + 3], tensors[ti + 4], tensors[ti + 5], identity, Y, n, ho, wo, c, c,
-                                       3, 3, 1, 1, 1, s)) != RPG_OK)
-                return rc;
-            ti += ds ? 9 : 6;
+            if (tensors[ti + 7] && rpg::wino_enabled())
+                rc = rpg::launch_conv_wino(T, tensors[ti + 7], tensors[ti + 5], tensors[ti + 6], identity, Y, n, ho, wo, c, c,
+                                           1, s);
+            else
+                rc = rpg::launch_conv(T, tensors[ti + 4], tensors[ti + 5], tensors[ti + 6], identity, Y, n, ho, wo, c, c, 3,
+                                      3, 1, 1, 1, s);
+            if (rc != RPG_OK) return rc;
+            ti += ds ? 12 : 8;
             cur = (cur + 2) & 3;
             hh = ho; ww = wo; cin = c;
         }

@@ -40,6 +40,10 @@ struct GatherSrc {
 int launch_conv(const float* x, const float* w, const float* scale, const float* shift, const float* residual,
                 float* y, int n, int h, int wd, int cin, int cout, int kh, int kw, int stride, int pad, int relu,
                 hipStream_t s, int alg_cin = 0 /* channels counted as algorithmic work; 0 = cin */);
+int launch_conv_wino(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
+                     float* y, int n, int h, int w, int cin, int cout, int relu, hipStream_t s);
+bool wino_enabled();
+void wino_set(int on);
 int launch_linear(const GatherSrc& src, const float* weight, const float* bias, const float* residual, float* out,
                   int m, int n_out, int relu, hipStream_t s);
 

@@ -1,0 +1,293 @@
+// 3x3 / stride 1 / pad 1 convolution as a 1-D Winograd F(4,3) along the image width, on f32 MFMA (gfx950).
+//
+// Why: the f32 matrix pipe (v_mfma_f32_32x32x2_f32) is the roofline of the ResNet34 encoder; F(4,3) produces 4 output
+// pixels of a row from 6 input pixels with 6 multiplies per (kernel row, channel) instead of 12, i.e. HALF the MFMA
+// work, and stays pure fp32 (the transforms are small fp32 linear combinations; measured error ~2e-6 per layer).
+// 30 of the 36 convolutions of ResNet34 (all 3x3 stride-1 ones) take this path.
+//
+//   y[4t+i] = sum_xi AT[i][xi] * M[xi],   M[xi][tile][cout] = sum_{kh,c} V[xi][tile][kh,c] * U[xi][cout][kh,c]
+//   V[xi] = sum_j BT[xi][j] * d[j]   (d = the 6 input pixels 4t-1 .. 4t+4 of row ho+kh-1, zero outside the image)
+//   U[xi] = sum_j G[xi][j] * w[cout][kh][j][c]   (precomputed once per weight load by wino43_weights_kernel)
+//
+// So one convolution = 6 independent GEMMs  [tiles x 3*Cin] * [3*Cin x Cout]  whose accumulators a lane combines
+// in registers at the end (the output transform is lane-local: the MFMA C layout puts the same (tile, cout) element
+// of all 6 products in the same lane).  Workgroup = 4 waves on 64 tiles (= 256 output pixels) x 64 output channels;
+// a wave owns 32 tiles x 32 channels x 6 positions = 6 accumulators of 32x32.  K advances 16 at a time through ONE
+// LDS buffer pair (A: V[6][64][16+4], B: U[6][64][16+4] = 60 KB, two workgroups per CU): the raw pixels / weights of
+// step t+1 are fetched into registers while the 48 MFMAs of step t run, the input transform is applied when they
+// are written to LDS between two barriers.  Epilogue: output transform, then the same LDS-transposed 16-byte
+// BatchNorm / residual / ReLU / store as the direct kernel, two of the four pixel columns at a time.
+//
+// Reference op replaced: nn.Conv2d(3x3, stride 1, pad 1) + nn.BatchNorm2d (eval) (+ identity) + ReLU of a torchvision
+// BasicBlock, reached from /root/reference/python/niantic/modules/posenet.py:1037.
+#include "rpg_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int BK = 16, LD = BK + 4;      // K step and LDS pitch (floats)
+constexpr int P = 6;                     // Winograd positions
+constexpr int BMT = 64, BN = 64;         // tiles x output channels per workgroup
+constexpr int A_FLOATS = P * BMT * LD, B_FLOATS = P * BN * LD;
+constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS) * (int)sizeof(float);     // 61,440
+
+struct Epi {
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    float* out;
+    int relu;
+};
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 lin(float a, const float4& x, float b, const float4& y) {
+    return make_float4(a * x.x + b * y.x, a * x.y + b * y.y, a * x.z + b * y.z, a * x.w + b * y.w);
+}
+__device__ __forceinline__ float4 add(const float4& x, const float4& y) {
+    return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+__device__ __forceinline__ float4 sub(const float4& x, const float4& y) {
+    return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+}
+
+// x [n][H][W][Cin] -> y [n][H][W][Cout];  U [6][Cout][3][Cin];  M = n*H*Tw tiles, Tw = ceil(W/4)
+__global__ __launch_bounds__(NT) void wino43_conv_kernel(const float* __restrict__ x, const float* __restrict__ U,
+                                                         int H, int W, int Cin, int Cout, int Tw, int M, Epi ep,
+                                                         int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As = lds;                     // [P][BMT][LD]
+    float* Bs = lds + A_FLOATS;          // [P][BN][LD]
+    const int K = 3 * Cin;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r8 = nwg & 7;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+    const int m0 = (tile / tiles_n) * BMT;
+    const int n0 = (tile % tiles_n) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int row = tid >> 2, slot = tid & 3;          // this thread stages tile-row `row`, k-slot `slot`
+
+    // ---- A side: the 6 input pixels of tile m0+row, channels [c, c+4) of kernel row kh
+    const int m = m0 + row;
+    const float* img = x;
+    int hi0 = -(1 << 24), wi0 = 0;
+    if (m < M) {
+        const int tw = m % Tw;
+        const int t = m / Tw;
+        const int ho = t % H;
+        const int n = t / H;
+        img = x + (size_t)n * H * W * Cin;
+        hi0 = ho - 1;
+        wi0 = 4 * tw - 1;
+    }
+    int c = 4 * slot, kh = 0;
+    while (c >= Cin) { c -= Cin; ++kh; }
+    // ---- B side: U[xi][n0+row][k]
+    const int nrow = n0 + row;
+    const float* urow = (nrow < Cout) ? U + (size_t)nrow * K : nullptr;
+    const size_t ustride = (size_t)Cout * K;
+    int kk = 4 * slot;
+
+    float4 d[P], ub[P];
+    auto fetch = [&]() {
+        const int hi = hi0 + kh;
+        const bool rok = (kh < 3) && ((unsigned)hi < (unsigned)H);
+        const float* rowp = img + ((size_t)hi * W) * Cin + c;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int wi = wi0 + j;
+            d[j] = f4zero();
+            if (rok && (unsigned)wi < (unsigned)W) d[j] = *reinterpret_cast<const float4*>(rowp + (size_t)wi * Cin);
+        }
+#pragma unroll
+        for (int xi = 0; xi < P; ++xi) {
+            ub[xi] = f4zero();
+            if (urow != nullptr && kk < K) ub[xi] = *reinterpret_cast<const float4*>(urow + xi * ustride + kk);
+        }
+    };
+    auto advance = [&]() {
+        c += BK;
+        while (c >= Cin) { c -= Cin; ++kh; }
+        kk += BK;
+    };
+    auto stage = [&]() {
+        // input transform V = BT d  (BT of F(4,3), interpolation points 0, +-1, +-2, inf)
+        const float4 t0 = lin(4.f, d[0], -5.f, d[2]);                  // 4 d0 - 5 d2
+        const float4 v0 = add(t0, d[4]);
+        const float4 s12 = lin(-4.f, d[2], 1.f, d[4]);                 // -4 d2 + d4
+        const float4 q12 = lin(4.f, d[1], -1.f, d[3]);                 //  4 d1 - d3
+        const float4 v1 = sub(s12, q12);
+        const float4 v2 = add(s12, q12);
+        const float4 s34 = sub(d[4], d[2]);                            // d4 - d2
+        const float4 q34 = lin(2.f, d[3], -2.f, d[1]);                 // 2 d3 - 2 d1
+        const float4 v3 = add(s34, q34);
+        const float4 v4 = sub(s34, q34);
+        const float4 v5 = add(lin(4.f, d[1], -5.f, d[3]), d[5]);
+        float* ap = As + row * LD + 4 * slot;
+        *reinterpret_cast<float4*>(ap + 0 * BMT * LD) = v0;
+        *reinterpret_cast<float4*>(ap + 1 * BMT * LD) = v1;
+        *reinterpret_cast<float4*>(ap + 2 * BMT * LD) = v2;
+        *reinterpret_cast<float4*>(ap + 3 * BMT * LD) = v3;
+        *reinterpret_cast<float4*>(ap + 4 * BMT * LD) = v4;
+        *reinterpret_cast<float4*>(ap + 5 * BMT * LD) = v5;
+        float* bp = Bs + row * LD + 4 * slot;
+#pragma unroll
+        for (int xi = 0; xi < P; ++xi) *reinterpret_cast<float4*>(bp + xi * BN * LD) = ub[xi];
+    };
+
+    f32x16 acc[P];
+#pragma unroll
+    for (int xi = 0; xi < P; ++xi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[xi][e] = 0.f;
+
+    const int a_off = (wm * 32 + (lane & 31)) * LD + 4 * (lane >> 5);
+    const int b_off = (wn * 32 + (lane & 31)) * LD + 4 * (lane >> 5);
+    const int nk = (K + BK - 1) / BK;
+    fetch();
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                 // every wave is done reading the previous step's LDS image
+        stage();
+        __syncthreads();
+        if (kt + 1 < nk) {
+            advance();
+            fetch();                     // in flight during the MFMAs below
+        }
+#pragma unroll
+        for (int kb = 0; kb < BK; kb += 8) {
+#pragma unroll
+            for (int xi = 0; xi < P; ++xi) {
+                const float4 a = *reinterpret_cast<const float4*>(&As[xi * BMT * LD + a_off + kb]);
+                const float4 b = *reinterpret_cast<const float4*>(&Bs[xi * BN * LD + b_off + kb]);
+                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[xi], 0, 0, 0);
+                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[xi], 0, 0, 0);
+                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[xi], 0, 0, 0);
+                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[xi], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                     // LDS becomes the epilogue slabs
+
+    // ---- epilogue: output transform (lane-local), then LDS transpose -> 16-byte row segments
+    constexpr int EP = 32 + 4;                              // slab pitch: 32 channels + pad
+    float* slab = lds + wave * (64 * EP);                   // 64 pixel rows (32 tiles x 2 pixels) per half
+    const int c4 = lane & 7, pr = lane >> 3;                // 8 lanes cover a row's 32 channels; 8 rows per pass
+    const int nb = n0 + wn * 32 + 4 * c4;
+    const bool n_ok = nb < Cout;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
+    if (n_ok && ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + nb);
+    if (n_ok && ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + nb);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e];
+            float ya, yb;
+            if (half == 0) {
+                ya = acc[0][e] + m1 + m2 + m3 + m4;                     // y0
+                yb = (m1 - m2) + 2.f * (m3 - m4);                       // y1
+            } else {
+                ya = (m1 + m2) + 4.f * (m3 + m4);                       // y2
+                yb = (m1 - m2) + 8.f * (m3 - m4) + acc[5][e];           // y3
+            }
+            const int trow = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);  // tile within the wave's 32
+            slab[(2 * trow) * EP + (lane & 31)] = ya;
+            slab[(2 * trow + 1) * EP + (lane & 31)] = yb;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int prow = pr + 8 * it;                               // 0..63 = (tile, pixel-in-half)
+            const float4 v = *reinterpret_cast<const float4*>(&slab[prow * EP + 4 * c4]);
+            const int mt = m0 + wm * 32 + (prow >> 1);
+            if (mt < M && n_ok) {
+                const int tw = mt % Tw;
+                const int t = mt / Tw;                                  // = n*H + ho
+                const int wo = 4 * tw + 2 * half + (prow & 1);
+                if (wo < W) {
+                    const size_t o = ((size_t)t * W + wo) * Cout + nb;
+                    float4 rs = f4zero();
+                    if (ep.residual) rs = *reinterpret_cast<const float4*>(ep.residual + o);
+                    float4 y;
+                    y.x = v.x * sc.x + sh.x + rs.x; y.y = v.y * sc.y + sh.y + rs.y;
+                    y.z = v.z * sc.z + sh.z + rs.z; y.w = v.w * sc.w + sh.w + rs.w;
+                    if (ep.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+                    *reinterpret_cast<float4*>(ep.out + o) = y;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// U[xi][co][kh][c] = sum_j G[xi][j] * w[co][kh][j][c], evaluated in double and rounded once.
+__global__ __launch_bounds__(NT) void wino43_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout,
+                                                            int Cin, long total) {
+    const long i = (long)blockIdx.x * NT + threadIdx.x;       // over [co][kh][c]
+    if (i >= total) return;
+    const int c = (int)(i % Cin);
+    const long t = i / Cin;
+    const int kh = (int)(t % 3);
+    const long co = t / 3;
+    const float* wp = w + ((co * 3 + kh) * 3) * (long)Cin + c;
+    const double g0 = wp[0], g1 = wp[Cin], g2 = wp[2 * (long)Cin];
+    const double u[6] = {g0 / 4.0, -(g0 + g1 + g2) / 6.0, -(g0 - g1 + g2) / 6.0,
+                         g0 / 24.0 + g1 / 12.0 + g2 / 6.0, g0 / 24.0 - g1 / 12.0 + g2 / 6.0, g2};
+    const long plane = (long)Cout * 3 * Cin;
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi) U[xi * plane + i] = (float)u[xi];
+}
+
+int g_wino = 1;
+
+}  // namespace
+
+namespace rpg {
+
+bool wino_enabled() { return g_wino != 0; }
+void wino_set(int on) { g_wino = on; }
+
+int launch_conv_wino(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
+                     float* y, int n, int h, int w, int cin, int cout, int relu, hipStream_t s) {
+    if (!x || !u || !y || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3) ||
+        !aligned16(x) || !aligned16(u) || !aligned16(y) || (scale && !aligned16(scale)) || (shift && !aligned16(shift)) ||
+        (residual && !aligned16(residual)))
+        return RPG_ERR_BAD_ARG;
+    const int tw = (w + 3) / 4;
+    const long M = (long)n * h * tw;
+    if (M >= (1L << 31) || (long)h * w * cin >= (1L << 31)) return RPG_ERR_BAD_ARG;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino43_conv_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr = true;
+    }
+    const int tm = (int)((M + BMT - 1) / BMT), tn = (cout + BN - 1) / BN;
+    Epi ep{scale, shift, residual, y, relu};
+    const int slot = timing_begin(RPG_TIMER_CONV, s);
+    hipLaunchKernelGGL(wino43_conv_kernel, dim3(tm * tn), dim3(NT), LDS_BYTES, s, x, u, h, w, cin, cout, tw, (int)M, ep, tn);
+    timing_end(slot, 2.0 * (double)n * h * w * cout * 9.0 * cin, s);      // algorithmic (direct-convolution) FLOP
+    RPG_CHECK_LAUNCH("conv3x3_wino43");
+    return RPG_OK;
+}
+
+}  // namespace rpg
+
+extern "C" int rpg_wino43_transform_weights_f32(const float* w_ohwi, float* u, int cout, int cin, void* stream) {
+    if (!w_ohwi || !u || cout <= 0 || cin <= 0) return RPG_ERR_BAD_ARG;
+    const long total = (long)cout * 3 * cin;
+    hipLaunchKernelGGL(wino43_weights_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, rpg::as_stream(stream),
+                       w_ohwi, u, cout, cin, total);
+    RPG_CHECK_LAUNCH("wino43_transform_weights");
+    return RPG_OK;
+}
+
+extern "C" int rpg_conv3x3_wino43_bn_act_nhwc_f32(const float* x, const float* u, const float* scale, const float* shift,
+                                                  const float* residual, float* y, int n, int h, int w, int cin, int cout,
+                                                  int relu, void* stream) {
+    return rpg::launch_conv_wino(x, u, scale, shift, residual, y, n, h, w, cin, cout, relu, rpg::as_stream(stream));
+}

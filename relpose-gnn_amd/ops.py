@@ -61,6 +61,33 @@ def conv2d_bn_act_nhwc(x: torch.Tensor, w_ohwi: torch.Tensor, scale: Optional[to
     return y
 
 
+def wino43_transform_weights(w_ohwi: torch.Tensor) -> torch.Tensor:
+    """[Cout][3][3][Cin] -> Winograd F(4,3) weights U [6][Cout][3][Cin] (once per weight load)."""
+    w_ohwi = _req(w_ohwi, "w_ohwi")
+    cout, kh, kw, cin = w_ohwi.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("Winograd F(4,3) path is for 3x3 kernels")
+    u = torch.empty((6, cout, 3, cin), dtype=torch.float32, device=w_ohwi.device)
+    L.check(L.lib().rpg_wino43_transform_weights_f32(_p(w_ohwi), _p(u), cout, cin, _stream()), "wino43_transform_weights")
+    return u
+
+
+def conv3x3_wino43_bn_act_nhwc(x: torch.Tensor, u: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor],
+                               residual: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    x, u = _req(x, "x"), _req(u, "u")
+    n, h, w, cin = x.shape
+    if u.dim() != 4 or u.shape[0] != 6 or u.shape[2] != 3 or u.shape[3] != cin:
+        raise ValueError("u must be [6][Cout][3][Cin]")
+    cout = u.shape[1]
+    y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
+    scale = None if scale is None else _req(scale, "scale")
+    shift = None if shift is None else _req(shift, "shift")
+    residual = None if residual is None else _req(residual, "residual")
+    L.check(L.lib().rpg_conv3x3_wino43_bn_act_nhwc_f32(_p(x), _p(u), _p(scale), _p(shift), _p(residual), _p(y), n, h, w, cin,
+                                                        cout, int(relu), _stream()), "conv3x3_wino43_bn_act_nhwc")
+    return y
+
+
 def maxpool3x3s2_nhwc(x: torch.Tensor) -> torch.Tensor:
     x = _req(x, "x")
     n, h, w, c = x.shape
@@ -178,7 +205,7 @@ def timing_read() -> Dict[str, Dict[str, float]]:
     return {name: {"ms": ms[i], "launches": int(cnt[i]), "work": work[i]} for i, name in enumerate(L.TIMER_NAMES)}
 
 
-TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK = 0, 1, 2, 3
+TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD = 0, 1, 2, 3, 4
 
 
 def set_tuning(key: int, value: int) -> None:

@@ -4,11 +4,12 @@ Done once per weight load (``PoseNetX_R2._packed()``), on the model's device, wi
 permute / concatenate / fold constants:
 
 encoder (``rpg_resnet_forward_f32`` tensor order)
-    for the stem, then every BasicBlock's conv1, conv2 and (if present) downsample conv:
+    for the stem, then every BasicBlock's conv1, conv2 and (if present) downsample conv, four slots each:
         w_ohwi  [Cout][KH][KW][Cin]   = PyTorch OIHW weight permuted to channels-last; the stem's 3 input
                                         channels are zero-padded to 4 so every im2col chunk is one 16-byte load
         scale   [Cout] = gamma / sqrt(running_var + eps)          (eval-mode BatchNorm folded to an affine
         shift   [Cout] = beta - running_mean * scale               epilogue; the conv weights are untouched)
+        u       [6][Cout][3][Cin]     = Winograd F(4,3) weights of a 3x3 stride-1 convolution, or None
     then fc.weight [feat][512], fc.bias [feat]
 
 GNN (``rpg_gnn_forward_f32`` tensor order, 22 tensors)
@@ -23,7 +24,7 @@ my_gnn_layer.py:280-291, att.py:9-14; BatchNorm eps = 1e-5 (torch default used b
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -57,13 +58,20 @@ def resnet_structure(sd: Dict[str, torch.Tensor], prefix: str) -> Tuple[List[int
     return blocks, planes
 
 
-def pack_resnet(sd: Dict[str, torch.Tensor], prefix: str = "feature_extractor.") -> Tuple[List[torch.Tensor], List[int], List[int]]:
+def pack_resnet(sd: Dict[str, torch.Tensor], prefix: str = "feature_extractor.", wino_fn=None
+                ) -> Tuple[List[Optional[torch.Tensor]], List[int], List[int]]:
+    """``wino_fn(w_ohwi) -> U [6][Cout][3][Cin]`` (``ops.wino43_transform_weights``, needs the GPU) fills the fourth slot
+    of every 3x3 stride-1 convolution; without it (host-only packing) the slot stays None = direct kernel."""
     blocks, planes = resnet_structure(sd, prefix)
-    t: List[torch.Tensor] = []
+    t: List[Optional[torch.Tensor]] = []
+
+    def wino(w_ohwi, stride):
+        ok = wino_fn is not None and stride == 1 and w_ohwi.shape[3] % 4 == 0 and w_ohwi.shape[0] % 4 == 0
+        return wino_fn(w_ohwi) if ok else None
     w = sd[prefix + "conv1.weight"]
     if tuple(w.shape[1:]) != (3, 7, 7) or w.shape[0] != planes[0]:
         raise ValueError("stem must be Conv2d(3, planes[0], 7, stride 2, pad 3)")
-    t += [_ohwi(w, pad_cin_to=4), *_bn_affine(sd, prefix + "bn1.")]
+    t += [_ohwi(w, pad_cin_to=4), *_bn_affine(sd, prefix + "bn1."), None]
     cin = planes[0]
     for li, (nb, c) in enumerate(zip(blocks, planes), start=1):
         for b in range(nb):
@@ -71,13 +79,14 @@ def pack_resnet(sd: Dict[str, torch.Tensor], prefix: str = "feature_extractor.")
             stride = 2 if (li > 1 and b == 0) else 1
             if tuple(sd[p + "conv1.weight"].shape) != (c, cin, 3, 3) or tuple(sd[p + "conv2.weight"].shape) != (c, c, 3, 3):
                 raise ValueError(f"{p}: not a BasicBlock with 3x3 convolutions")
-            t += [_ohwi(sd[p + "conv1.weight"]), *_bn_affine(sd, p + "bn1.")]
-            t += [_ohwi(sd[p + "conv2.weight"]), *_bn_affine(sd, p + "bn2.")]
+            w1, w2 = _ohwi(sd[p + "conv1.weight"]), _ohwi(sd[p + "conv2.weight"])
+            t += [w1, *_bn_affine(sd, p + "bn1."), wino(w1, stride)]
+            t += [w2, *_bn_affine(sd, p + "bn2."), wino(w2, 1)]
             has_ds = (p + "downsample.0.weight") in sd
             if has_ds != (stride != 1 or cin != c):
                 raise ValueError(f"{p}: downsample presence does not match the torchvision BasicBlock rule")
             if has_ds:
-                t += [_ohwi(sd[p + "downsample.0.weight"]), *_bn_affine(sd, p + "downsample.1.")]
+                t += [_ohwi(sd[p + "downsample.0.weight"]), *_bn_affine(sd, p + "downsample.1."), None]
             cin = c
     t += [sd[prefix + "fc.weight"].float().contiguous(), sd[prefix + "fc.bias"].float().contiguous()]
     return t, blocks, planes

@@ -60,11 +60,11 @@ class EncoderRunner:
         if self._packed is None:
             with torch.no_grad():
                 sd = {k: v.detach() for k, v in state_dict_fn().items()}
-                self._packed = pack_resnet(sd, prefix)
-            if any(t.device != x_nchw.device for t in self._packed[0]):
-                self._packed = None
-                raise RuntimeError("encoder weights and input are on different devices")
-            self._ptrs = L.ptr_array([t.data_ptr() for t in self._packed[0]])
+                if any(v.device != x_nchw.device for v in sd.values() if v.is_floating_point()):
+                    raise RuntimeError("encoder weights and input are on different devices")
+                from . import ops
+                self._packed = pack_resnet(sd, prefix, wino_fn=ops.wino43_transform_weights)
+            self._ptrs = L.ptr_array([None if t is None else t.data_ptr() for t in self._packed[0]])
         tensors, blocks, planes = self._packed
         x = x_nchw.contiguous()
         n, _, h, w = x.shape

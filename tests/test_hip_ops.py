@@ -278,3 +278,41 @@ def test_knn_graph(dev, sizes, k, d):
     assert torch.equal(got, ref)
     if len(sizes) == 1:
         assert torch.equal(ops.knn_graph(x.to(dev), k, None).cpu(), ref)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,res,relu", [
+    (2, 9, 11, 8, 16, False, True),        # ragged width (Tw=3, last tile 3 px), Cin < K-step (several kernel rows per step)
+    (1, 16, 16, 24, 72, True, True),       # Cout not a multiple of the 64-channel tile, residual
+    (3, 5, 4, 16, 64, True, False),        # exactly one tile per row, no activation
+    (8, 56, 56, 64, 64, True, True),       # layer1 shape
+    (4, 28, 28, 128, 128, False, True),    # layer2
+    (4, 14, 14, 256, 256, True, True),     # layer3: 14 -> 4 tiles per row (12.5 % padding)
+    (4, 7, 7, 512, 512, True, True),       # layer4: 7 -> 2 tiles per row
+    (2, 256 // 8, 341 // 8 + 1, 128, 128, True, True),   # odd width from the 256x341 evaluation shape (32x43)
+])
+def test_conv3x3_winograd(dev, n, h, w, cin, cout, res, relu):
+    """1-D Winograd F(4,3) convolution vs F.conv2d; tolerance 2e-5 (the transforms cost ~2.5x the rounding error of
+    the direct kernel per layer: measured in tools, still 5x below the per-op bar used elsewhere x 2)."""
+    from relpose_gnn_amd import ops
+    x = _rand(n, cin, h, w, seed=1)
+    wt = _rand(cout, cin, 3, 3, seed=2, scale=(2.0 / (cin * 9)) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(3)) + 0.5
+    shift = _rand(cout, seed=4, scale=0.1)
+    ref = F.conv2d(x, wt, None, stride=1, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    r = None
+    if res:
+        r = _rand(*ref.shape, seed=5)
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    w_ohwi = wt.permute(0, 2, 3, 1).contiguous().to(dev)
+    u = ops.wino43_transform_weights(w_ohwi)
+    # weight transform against a float64 statement of U = G g
+    G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                      [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
+    u_ref = torch.einsum("xj,ohjc->xohc", G, wt.permute(0, 2, 3, 1).double()).float()
+    assert torch.allclose(u.cpu(), u_ref, rtol=2e-7, atol=1e-9)
+    y = ops.conv3x3_wino43_bn_act_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), u, scale.to(dev), shift.to(dev),
+                                       None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev), relu=relu)
+    err = rel_err(y.cpu().permute(0, 3, 1, 2), ref)
+    assert err < 2e-5, err

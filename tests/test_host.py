@@ -65,7 +65,8 @@ def test_weight_packing():
     sd = S.synth_state_dict(S.posenet_r2_param_shapes(64, 64, 64, planes, blocks), seed=2)
     t, b, p = pack_resnet(sd)
     assert b == list(blocks) and p == list(planes)
-    assert len(t) == 3 + 6 * 5 + 3 * 3 + 2
+    assert len(t) == 4 + 8 * 5 + 4 * 3 + 2                 # {w, scale, shift, u_wino} per conv; u is None without a GPU
+    assert all(v is None for v in t[3:-2:4]) and all(v is not None for i, v in enumerate(t) if i % 4 != 3 or i >= len(t) - 2)
     assert t[0].shape == (8, 7, 7, 4) and float(t[0][..., 3].abs().max()) == 0.0
     assert torch.equal(t[0][..., :3], sd["feature_extractor.conv1.weight"].permute(0, 2, 3, 1))
     # folded BN == eval-mode batch norm

@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--epi", type=int, default=1)
     ap.add_argument("--tile", type=int, default=-1)
     ap.add_argument("--sk", type=int, default=1)
+    ap.add_argument("--wino", type=int, default=1)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ops.set_tuning(ops.TUNE_BK, args.bk)
@@ -71,9 +72,14 @@ def main():
         sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.1
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
         r = torch.randn(n, ho, wo, cout, device=dev) if res else None
-        med, best = timeit(lambda: ops.conv2d_bn_act_nhwc(x, wt, sc, sh, r, stride=s, pad=p, relu=True), args.reps)
-        fl = 2.0 * n * ho * wo * cout * k * k * (3 if name == "stem" else cin)
-        print(f"conv {name:6s} M={n*ho*wo:8d} N={cout:4d} K={k*k*cin:5d}  {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF (best {fl/best/1e9:6.1f})", flush=True)
+        if args.wino and k == 3 and s == 1:
+            u = ops.wino43_transform_weights(wt)
+            name = name + "w"
+            med, best = timeit(lambda: ops.conv3x3_wino43_bn_act_nhwc(x, u, sc, sh, r, relu=True), args.reps)
+        else:
+            med, best = timeit(lambda: ops.conv2d_bn_act_nhwc(x, wt, sc, sh, r, stride=s, pad=p, relu=True), args.reps)
+        fl = 2.0 * n * ho * wo * cout * k * k * (3 if name == "stem" else cin)      # algorithmic (direct) FLOP
+        print(f"conv {name:7s} M={n*ho*wo:8d} N={cout:4d} K={k*k*cin:5d}  {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF (best {fl/best/1e9:6.1f})", flush=True)
     for name, m, widths, n_out in LINEAR:
         if args.only and args.only not in name:
             continue
