@@ -110,7 +110,8 @@ extern "C" int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors
             float* Y = buf[(cur + 2) & 3];
             float* D = buf[(cur + 3) & 3];
             // conv1 3x3/stride + BN + ReLU
-            if (stride == 1 && tensors[ti + 3] && rpg::wino_enabled())
+            const bool wino_fits = (long)hh * ww * (cin > c ? cin : c) * 4 * 66 < (1L << 31);   // 32-bit buffer offsets
+            if (stride == 1 && tensors[ti + 3] && rpg::wino_enabled() && wino_fits)
                 rc = rpg::launch_conv_wino(X, tensors[ti + 3], tensors[ti + 1], tensors[ti + 2], nullptr, T, n, hh, ww, cin,
                                            c, 1, s);
             else
@@ -125,7 +126,7 @@ extern "C" int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors
                 identity = D;
             }
             // conv2 3x3/1 + BN + identity + ReLU
-            if (tensors[ti + 7] && rpg::wino_enabled())
+            if (tensors[ti + 7] && rpg::wino_enabled() && wino_fits)
                 rc = rpg::launch_conv_wino(T, tensors[ti + 7], tensors[ti + 5], tensors[ti + 6], identity, Y, n, ho, wo, c, c,
                                            1, s);
             else

@@ -53,7 +53,7 @@ __device__ __forceinline__ float4 sub(const float4& x, const float4& y) {
 }
 
 // x [n][H][W][Cin] -> y [n][H][W][Cout];  U [6][Cout][3][Cin];  M = n*H*Tw tiles, Tw = ceil(W/4)
-__global__ __launch_bounds__(NT) void wino43_conv_kernel(const float* __restrict__ x, const float* __restrict__ U,
+__global__ __launch_bounds__(NT, 2) void wino43_conv_kernel(const float* __restrict__ x, const float* __restrict__ U,
                                                          int H, int W, int Cin, int Cout, int Tw, int M, Epi ep,
                                                          int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -71,16 +71,25 @@ __global__ __launch_bounds__(NT) void wino43_conv_kernel(const float* __restrict
     const int wm = wave >> 1, wn = wave & 1;
     const int row = tid >> 2, slot = tid & 3;          // this thread stages tile-row `row`, k-slot `slot`
 
-    // ---- A side: the 6 input pixels of tile m0+row, channels [c, c+4) of kernel row kh
+    // ---- A side: the 6 input pixels of tile m0+row, channels [c, c+4) of kernel row kh.
+    // All global reads are raw buffer loads: an out-of-range lane gets offset 0x80000000 >= num_records and the
+    // hardware returns zeros, so image borders, the K tail and ragged tiles cost neither a branch nor a select and
+    // the 12 loads of a step are one straight-line block.  The A descriptor is based at the first image this
+    // workgroup touches (wave-uniform), so 32-bit byte offsets suffice for any batch size.
+    const int n_first = (m0 / Tw) / H;
+    const size_t img_floats = (size_t)H * W * Cin;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + n_first * img_floats), 0,
+                                                                         0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, 0x7fffffff, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
     const int m = m0 + row;
-    const float* img = x;
-    int hi0 = -(1 << 24), wi0 = 0;
+    int img_off = 0, hi0 = -(1 << 24), wi0 = 0;
     if (m < M) {
         const int tw = m % Tw;
         const int t = m / Tw;
         const int ho = t % H;
         const int n = t / H;
-        img = x + (size_t)n * H * W * Cin;
+        img_off = (n - n_first) * (int)img_floats;
         hi0 = ho - 1;
         wi0 = 4 * tw - 1;
     }
@@ -88,25 +97,30 @@ __global__ __launch_bounds__(NT) void wino43_conv_kernel(const float* __restrict
     while (c >= Cin) { c -= Cin; ++kh; }
     // ---- B side: U[xi][n0+row][k]
     const int nrow = n0 + row;
-    const float* urow = (nrow < Cout) ? U + (size_t)nrow * K : nullptr;
-    const size_t ustride = (size_t)Cout * K;
+    const bool nrow_ok = nrow < Cout;
+    const unsigned ustride_b = (unsigned)Cout * K * 4u;
     int kk = 4 * slot;
 
     float4 d[P], ub[P];
     auto fetch = [&]() {
+        // validity as 0 / ~0 masks combined with bit operations: no short-circuit control flow for the compiler to
+        // thread branches through
         const int hi = hi0 + kh;
-        const bool rok = (kh < 3) && ((unsigned)hi < (unsigned)H);
-        const float* rowp = img + ((size_t)hi * W) * Cin + c;
+        const unsigned rmask = 0u - ((unsigned)(kh < 3) & (unsigned)((unsigned)hi < (unsigned)H));
+        const int row_off = img_off + hi * W * Cin + c;
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const int wi = wi0 + j;
-            d[j] = f4zero();
-            if (rok && (unsigned)wi < (unsigned)W) d[j] = *reinterpret_cast<const float4*>(rowp + (size_t)wi * Cin);
+            const unsigned mask = rmask & (0u - (unsigned)((unsigned)wi < (unsigned)W));
+            const unsigned off = ((4u * (unsigned)(row_off + wi * Cin)) & mask) | (OOB & ~mask);
+            d[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
         }
+        const unsigned umask = 0u - ((unsigned)nrow_ok & (unsigned)(kk < K));
+        const unsigned uoff = 4u * (unsigned)(nrow * K + kk);
 #pragma unroll
         for (int xi = 0; xi < P; ++xi) {
-            ub[xi] = f4zero();
-            if (urow != nullptr && kk < K) ub[xi] = *reinterpret_cast<const float4*>(urow + xi * ustride + kk);
+            const unsigned off = ((uoff + xi * ustride_b) & umask) | (OOB & ~umask);
+            ub[xi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 0));
         }
     };
     auto advance = [&]() {
@@ -259,7 +273,9 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
         return RPG_ERR_BAD_ARG;
     const int tw = (w + 3) / 4;
     const long M = (long)n * h * tw;
-    if (M >= (1L << 31) || (long)h * w * cin >= (1L << 31)) return RPG_ERR_BAD_ARG;
+    // 32-bit buffer offsets: a workgroup's 64 tiles span at most 65 images; U is addressed from its base
+    if (M >= (1L << 31) || (long)h * w * cin * 4 * 66 >= (1L << 31) || 6L * cout * 3 * cin * 4 >= (1L << 31))
+        return RPG_ERR_BAD_ARG;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino43_conv_kernel),
