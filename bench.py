@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--graphs", type=int, default=32, help="graphs per step per GPU (configs[1]: 32)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU the batch is spread over in the timed region")
     return ap.parse_args()
 
 
@@ -99,6 +100,7 @@ def main():
     sd = S.synth_state_dict(S.posenet_r2_param_shapes(D, D, D), seed=1)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
+    model.hip_streams = args.streams
 
     B = args.graphs
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -116,24 +118,34 @@ def main():
         out = step()
     torch.cuda.synchronize()
 
-    timing = not args.no_kernel_timing
-    if timing:
+    def timed(n_steps):
+        nonlocal out
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return time.perf_counter() - t0
+
+    # pass 1: the K timed steps that define `value` (no instrumentation inside the region)
+    elapsed = timed(args.steps)
+    # pass 2 (roofline): the same K steps again on ONE stream, every launch of the hot kernels bracketed by HIP events
+    # on its launch stream.  One stream, because with two the kernels of the two batch halves overlap and a launch's
+    # duration would include sharing the GPU; and outside pass 1, because hipEventRecord costs a few % of the step.
+    kt, elapsed_ev = None, None
+    if not args.no_kernel_timing:
+        model.hip_streams = 1
+        step()                         # workspaces for the unsplit batch
         ops.timing_read()              # drop anything recorded so far
         ops.timing_enable(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kt = None
-    if timing:
+        elapsed_ev = timed(args.steps)
         ops.timing_enable(False)
         kt = ops.timing_read()
+        model.hip_streams = args.streams
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -150,7 +162,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: batch=32 8-node fully-connected graphs per GPU, 224x224 RGB, "
                                    "fp32, ResNet34 + GNN (D=2048, gnn_recursion=2, droprate=0, eval), random-init weights",
                        "graphs_per_step_per_gpu": B, "nodes_per_graph": NODES, "edges_per_graph": NODES * (NODES - 1),
-                       "image": [IMG, IMG], "parallelism": f"graph-sharded x{world}, all-gather of rel poses per step"},
+                       "image": [IMG, IMG], "streams_per_gpu": args.streams,
+                       "parallelism": f"graph-sharded x{world}, all-gather of rel poses per step"},
         }
         if kt is not None and kt["conv"]["launches"]:
             c = kt["conv"]
@@ -158,10 +171,15 @@ def main():
             line["roofline"] = {
                 "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
-                "kernel": "gemm_tile_kernel<ConvLoader> (implicit-GEMM conv+BN+ReLU, v_mfma_f32_32x32x2_f32)",
+                "kernel": "conv+BN(+residual)+ReLU on v_mfma_f32_32x32x2_f32: wino43_conv_kernel (30 3x3/s1 layers) + "
+                          "gemm_tile/streamk kernels<ConvLoader> (stem, 3 strided 3x3, 3 1x1)",
                 "launches": c["launches"], "avg_launch_ms": round(c["ms"] / c["launches"], 4),
                 "alg_gflop_per_launch": round(c["work"] / c["launches"] / 1e9, 3),
-                "share_of_step_time": round(c["ms"] / (1e3 * elapsed), 4),
+                "share_of_instrumented_step_time": round(c["ms"] / (1e3 * elapsed_ev), 4),
+                "measured_on": f"{args.steps} further steps of the same workload, one stream, per-launch HIP events: "
+                               f"{round(1e3 * elapsed_ev / args.steps, 3)} ms/step, vs "
+                               f"{round(1e3 * elapsed / args.steps, 3)} ms/step in the timed region "
+                               f"({args.streams} concurrent streams, no events)",
             }
             other = {}
             for k in ("linear", "attention", "scatter"):
@@ -177,7 +195,7 @@ def main():
                     tf = v["work"] / (v["ms"] * 1e-3) / 1e12
                     other[k] = {"achieved": round(tf, 2), "unit": "TFLOP/s", "launches": v["launches"],
                                 "avg_launch_ms": round(v["ms"] / v["launches"], 5),
-                                "share_of_step_time": round(v["ms"] / (1e3 * elapsed), 4)}
+                                "share_of_instrumented_step_time": round(v["ms"] / (1e3 * elapsed_ev), 4)}
             line["other_kernels"] = other
         if world == 1 and args.cpu_baseline_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(sd, args.cpu_baseline_seconds)

@@ -88,7 +88,10 @@ int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors, const int
 /* GNN primitives                                                                                */
 /* ------------------------------------------------------------------------------------------- */
 
-/* Index preparation for one edge_index [2][e] (row 0 = source, row 1 = target):
+/* Index preparation for one edge list given as its two rows src[e] (message source) and dst[e] (target) -- for a
+ * contiguous edge_index [2][E] pass edge_index and edge_index + E; for a column slice [e0, e1) of a batched edge_index
+ * pass edge_index + e0 and edge_index + E + e0 with node_offset = first node id of the slice (ids are stored
+ * relative to the whole batch, the kernels work on ids - node_offset in [0, n)):
  *   ends [4][e]    int64: sanitised source, sanitised target, min(s,t), max(s,t)
  *                  (the last two are compute_edge_features' gather indices, posenet.py:1014-1017)
  *   rowptr [n+1], perm [e]   CSR of edges grouped by TARGET node, edge ids ascending inside a
@@ -98,8 +101,8 @@ int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors, const int
  *                  left out of the CSR and their endpoints clamped, so no later kernel reads out
  *                  of bounds.  The host mirror raises IndexError when it is non-zero.
  * Single workgroup; e and n up to 2^20.                                                          */
-int rpg_graph_prepare(const int64_t* edge_index, int e, int n, int64_t* ends, int32_t* rowptr,
-                      int32_t* cursor, int32_t* perm, int32_t* status, void* stream);
+int rpg_graph_prepare(const int64_t* src, const int64_t* dst, int64_t node_offset, int e, int n, int64_t* ends,
+                      int32_t* rowptr, int32_t* cursor, int32_t* perm, int32_t* status, void* stream);
 
 /* torch_cluster.knn_graph(x, k, batch, loop=False, flow='source_to_target') (posenet.py:1043-1050): for every node
  * the k nearest OTHER nodes of its graph by squared Euclidean distance (k+1 nearest including itself by
@@ -140,14 +143,15 @@ int rpg_pose_heads_f32(const float* x, const float* w6, const float* b6, int r, 
 
 /* Everything after the encoder for use_gnn=True, use_AP=True, knn<=0 (posenet.py:1052-1091).
  * `tensors` HOST array of device pointers, order in params.py.
- * feat [n][d], edge_index [2][e] -> abs_pose [n][6], rel_pose [e][6].
+ * feat [n][d], edge rows src[e] / dst[e] with node_offset (see rpg_graph_prepare) -> abs_pose [n][6], rel_pose [e][6].
  * node_out [n][d] / edge_out [e][d]: optional (NULL to skip) copies of the final ReLU'd node and
  * edge features, i.e. the inputs of the heads; the host mirror uses them to apply the reference's
  * always-on F.dropout (posenet.py:1073-1075) before calling rpg_pose_heads_f32 itself.
  * status: device int32, see rpg_graph_prepare.                                                  */
 size_t rpg_gnn_workspace_bytes(int n, int e, int d);
-int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, const float* feat, const int64_t* edge_index,
-                        int n, int e, int d, int gnn_recursion, float* abs_pose, float* rel_pose,
+int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, const float* feat, const int64_t* src,
+                        const int64_t* dst, int64_t node_offset, int n, int e, int d, int gnn_recursion,
+                        float* abs_pose, float* rel_pose,
                         float* node_out, float* edge_out, int32_t* status, void* workspace,
                         size_t workspace_bytes, void* stream);
 

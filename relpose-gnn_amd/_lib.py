@@ -49,7 +49,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.rpg_resnet_workspace_bytes.restype = _sz
     lib.rpg_resnet_forward_f32.argtypes = [C.POINTER(_vp), _i, C.POINTER(_i), C.POINTER(_i), _i, _vp, _i, _i, _i, _vp,
                                            _vp, _sz, _vp]
-    lib.rpg_graph_prepare.argtypes = [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.rpg_graph_prepare.argtypes = [_vp, _vp, C.c_int64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.rpg_edge_concat_gather_f32.argtypes = [_vp, _vp, _i, _i, _vp, _vp]
     lib.rpg_linear_gather_f32.argtypes = [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), _vp, _vp,
                                           _vp, _vp, _i, _i, _i, _vp]
@@ -58,8 +58,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.rpg_pose_heads_f32.argtypes = [_vp, _vp, _vp, _i, _i, _vp, _vp]
     lib.rpg_gnn_workspace_bytes.argtypes = [_i, _i, _i]
     lib.rpg_gnn_workspace_bytes.restype = _sz
-    lib.rpg_gnn_forward_f32.argtypes = [C.POINTER(_vp), _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                                        _sz, _vp]
+    lib.rpg_gnn_forward_f32.argtypes = [C.POINTER(_vp), _i, _vp, _vp, _vp, C.c_int64, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
+                                        _vp, _vp, _sz, _vp]
     lib.rpg_timing_enable.argtypes = [_i]
     lib.rpg_set_tuning.argtypes = [_i, _i]
     lib.rpg_wino43_transform_weights_f32.argtypes = [_vp, _vp, _i, _i, _vp]

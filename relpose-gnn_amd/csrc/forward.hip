@@ -177,11 +177,11 @@ extern "C" size_t rpg_gnn_workspace_bytes(int n, int e, int d) {
     return gnn_bytes(n, e, d);
 }
 
-extern "C" int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, const float* feat,
-                                   const int64_t* edge_index, int n, int e, int d, int gnn_recursion, float* abs_pose,
+extern "C" int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, const float* feat, const int64_t* esrc,
+                                   const int64_t* edst, int64_t node_offset, int n, int e, int d, int gnn_recursion, float* abs_pose,
                                    float* rel_pose, float* node_out, float* edge_out, int32_t* status, void* workspace,
                                    size_t workspace_bytes, void* stream) {
-    if (!tensors || n_tensors != T_COUNT || !feat || !edge_index || !abs_pose || !rel_pose || !status || !workspace ||
+    if (!tensors || n_tensors != T_COUNT || !feat || !esrc || !edst || !abs_pose || !rel_pose || !status || !workspace ||
         n <= 0 || e <= 0 || d <= 0 || (d & 31) || gnn_recursion < 0)
         return RPG_ERR_BAD_ARG;
     for (int i = 0; i < T_COUNT; ++i)
@@ -206,7 +206,7 @@ extern "C" int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, c
     float* xbuf[2] = {cv.take<float>((size_t)n * d), cv.take<float>((size_t)n * d)};
 
     int rc;
-    if ((rc = rpg_graph_prepare(edge_index, e, n, ends, rowptr, cursor, perm, status, stream)) != RPG_OK) return rc;
+    if ((rc = rpg_graph_prepare(esrc, edst, node_offset, e, n, ends, rowptr, cursor, perm, status, stream)) != RPG_OK) return rc;
     const int64_t* src = ends;
     const int64_t* dst = ends + e;
     const int64_t* lo = ends + 2 * (size_t)e;

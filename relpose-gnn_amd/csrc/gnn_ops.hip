@@ -19,8 +19,9 @@ constexpr int NT = 256;
 // ------------------------------------------------------------------------------------------------
 constexpr int GP_NT = 1024;
 
-__global__ __launch_bounds__(GP_NT) void graph_prepare_kernel(const int64_t* __restrict__ ei, int E, int N,
-                                                              int64_t* __restrict__ ends, int* rowptr, int* cursor,
+__global__ __launch_bounds__(GP_NT) void graph_prepare_kernel(const int64_t* __restrict__ esrc,
+                                                              const int64_t* __restrict__ edst, int64_t node_off, int E,
+                                                              int N, int64_t* __restrict__ ends, int* rowptr, int* cursor,
                                                               int* perm, int* status) {
     __shared__ int s_scan[GP_NT];
     __shared__ int s_bad;
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(GP_NT) void graph_prepare_kernel(const int64_t* __r
     // pass 1: sanitised endpoints, min/max endpoints, in-degree histogram (rowptr[t+1] += 1)
     int bad = 0;
     for (int e = tid; e < E; e += GP_NT) {
-        const int64_t s = ei[e], t = ei[(size_t)E + e];
+        const int64_t s = esrc[e] - node_off, t = edst[e] - node_off;
         const bool ok = ((uint64_t)s < (uint64_t)N) && ((uint64_t)t < (uint64_t)N);
         const int64_t sc = s < 0 ? 0 : (s >= N ? N - 1 : s);
         const int64_t tc = t < 0 ? 0 : (t >= N ? N - 1 : t);
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(GP_NT) void graph_prepare_kernel(const int64_t* __r
 
     // pass 2: claim a slot inside the target's segment (arbitrary order) ...
     for (int e = tid; e < E; e += GP_NT) {
-        const int64_t s = ei[e], t = ei[(size_t)E + e];
+        const int64_t s = esrc[e] - node_off, t = edst[e] - node_off;
         if (((uint64_t)s < (uint64_t)N) && ((uint64_t)t < (uint64_t)N)) {
             const int slot = atomicAdd(&cursor[t], 1);
             perm[rowptr[t] + slot] = e;
@@ -343,12 +344,12 @@ int launch_relu_inplace(float* x, long n_floats, hipStream_t s) {
 }
 }  // namespace rpg
 
-extern "C" int rpg_graph_prepare(const int64_t* edge_index, int e, int n, int64_t* ends, int32_t* rowptr,
-                                 int32_t* cursor, int32_t* perm, int32_t* status, void* stream) {
-    if (!edge_index || !ends || !rowptr || !cursor || !perm || !status || e <= 0 || n <= 0 || e > (1 << 20) ||
+extern "C" int rpg_graph_prepare(const int64_t* src, const int64_t* dst, int64_t node_offset, int e, int n, int64_t* ends,
+                                 int32_t* rowptr, int32_t* cursor, int32_t* perm, int32_t* status, void* stream) {
+    if (!src || !dst || !ends || !rowptr || !cursor || !perm || !status || e <= 0 || n <= 0 || e > (1 << 20) ||
         n > (1 << 20))
         return RPG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(graph_prepare_kernel, dim3(1), dim3(GP_NT), 0, rpg::as_stream(stream), edge_index, e, n, ends,
+    hipLaunchKernelGGL(graph_prepare_kernel, dim3(1), dim3(GP_NT), 0, rpg::as_stream(stream), src, dst, node_offset, e, n, ends,
                        rowptr, cursor, perm, status);
     RPG_CHECK_LAUNCH("graph_prepare");
     return RPG_OK;

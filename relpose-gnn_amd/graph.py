@@ -40,6 +40,9 @@ class Data:
 
     @property
     def num_graphs(self) -> int:
+        gs = getattr(self, "graph_sizes", None)
+        if gs is not None:
+            return len(gs[0])
         return 1 if self.batch is None else int(self.batch.max().item()) + 1
 
     def __len__(self) -> int:              # test.py:207 uses len(data)
@@ -70,10 +73,14 @@ class Batch(Data):
                 eas.append(d.edge_attr)
             bs.append(torch.full((n,), g, dtype=torch.int64))
             off += n
-        return cls(x=torch.cat(xs, 0), edge_index=torch.cat(eis, 1),
-                   y=torch.cat(ys, 0) if len(ys) == len(graphs) else None,
-                   edge_attr=torch.cat(eas, 0) if len(eas) == len(graphs) else None,
-                   batch=torch.cat(bs, 0))
+        out = cls(x=torch.cat(xs, 0), edge_index=torch.cat(eis, 1),
+                  y=torch.cat(ys, 0) if len(ys) == len(graphs) else None,
+                  edge_attr=torch.cat(eas, 0) if len(eas) == len(graphs) else None,
+                  batch=torch.cat(bs, 0))
+        # host-side slice table (nodes / edges per graph): lets the HIP module cut the batch at graph boundaries and run
+        # the parts concurrently on several streams without a device round trip
+        out.graph_sizes = ([d.num_nodes for d in graphs], [int(d.edge_index.shape[1]) for d in graphs])
+        return out
 
 
 def fc_batch(x: torch.Tensor, nodes_per_graph: int, y: Optional[torch.Tensor] = None) -> Batch:
@@ -88,4 +95,6 @@ def fc_batch(x: torch.Tensor, nodes_per_graph: int, y: Optional[torch.Tensor] = 
     edge_attr = None
     if y is not None:
         edge_attr = y[edge_index[1]] - y[edge_index[0]]      # dataset_7Scenes_multi.py:425-429
-    return Batch(x=x, edge_index=edge_index.to(x.device), y=y, edge_attr=edge_attr, batch=batch.to(x.device))
+    out = Batch(x=x, edge_index=edge_index.to(x.device), y=y, edge_attr=edge_attr, batch=batch.to(x.device))
+    out.graph_sizes = ([nodes_per_graph] * b, [ei.shape[1]] * b)
+    return out

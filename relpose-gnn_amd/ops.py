@@ -115,8 +115,8 @@ def graph_prepare(edge_index: torch.Tensor, n: int) -> Dict[str, torch.Tensor]:
     cursor = torch.empty(n, dtype=torch.int32, device=dev)
     perm = torch.empty(e, dtype=torch.int32, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
-    L.check(L.lib().rpg_graph_prepare(_p(ei), e, n, _p(ends), _p(rowptr), _p(cursor), _p(perm), _p(status), _stream()),
-            "graph_prepare")
+    L.check(L.lib().rpg_graph_prepare(ei.data_ptr(), ei.data_ptr() + 8 * e, 0, e, n, _p(ends), _p(rowptr), _p(cursor), _p(perm),
+                                      _p(status), _stream()), "graph_prepare")
     return {"ends": ends, "rowptr": rowptr, "perm": perm, "status": status}
 
 

@@ -102,6 +102,11 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
                 if m.bias is not None:
                     nn.init.constant_(m.bias.data, 0)
 
+        # Number of HIP streams a batch is spread over (graphs are independent: the batch is cut at graph boundaries
+        # and the parts run concurrently, which fills the tile-quantisation tails of one part's kernels with the other
+        # part's work).  Needs the host-side slice table of relpose_gnn_amd.graph.Batch; other inputs use one stream.
+        self.hip_streams = 2
+        self._streams: List[torch.cuda.Stream] = []
         self._enc = EncoderRunner()
         self._gnn_packed: Optional[List[torch.Tensor]] = None
         self._gnn_ptrs = None
@@ -132,16 +137,7 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         """Relative pose targets p[src] - p[dst] (posenet.py:1021-1031; training-side helper, plain indexing)."""
         return p[edge_index[0]] - p[edge_index[1]]
 
-    @torch.no_grad()
-    def forward(self, data, k=None):
-        x, edge_index = data.x, data.edge_index
-        if not x.is_cuda:
-            raise RuntimeError("PoseNetX_R2 (HIP) needs its inputs on the GPU: call data.to(device) first "
-                               "(there is no CPU fallback)")
-        lib = _L.lib()
-        x = x.view(x.size(0), 3, self.input_img_height, -1)                       # posenet.py:1035
-        feat = self._enc.run(self.feature_extractor.state_dict, "", x)            # posenet.py:1037
-
+    def _pack_gnn(self):
         if self._gnn_packed is None:
             sd = {kk: v.detach() for kk, v in self.state_dict().items() if not kk.startswith("feature_extractor.")}
             if not self.use_AP:        # the node heads take pair features: pack them separately, keep slots 18/19 valid
@@ -155,6 +151,51 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
                 self._extra["att_w"], self._extra["att_b"] = sd["att.W.weight"].float().contiguous(), sd["att.W.bias"].float().contiguous()
             self._gnn_packed = pack_gnn(sd)
             self._gnn_ptrs = _L.ptr_array([t.data_ptr() for t in self._gnn_packed])
+
+    def _gnn_call(self, lib, feat, esrc_ptr, edst_ptr, node_off, n, e, abs_pose, rel_pose, node_f, edge_f, status, slot):
+        d = feat.shape[1]
+        key = (n, e, d, feat.device)
+        ent = self._gnn_ws.get(slot)
+        if ent is None or ent[0] != key:
+            ent = (key, torch.empty(lib.rpg_gnn_workspace_bytes(n, e, d), dtype=torch.uint8, device=feat.device))
+            self._gnn_ws[slot] = ent
+        ws = ent[1]
+        rc = lib.rpg_gnn_forward_f32(self._gnn_ptrs, len(self._gnn_packed), feat.data_ptr(), esrc_ptr, edst_ptr, node_off, n,
+                                     e, d, int(self.gnn_recursion), abs_pose.data_ptr(), rel_pose.data_ptr(),
+                                     None if node_f is None else node_f.data_ptr(),
+                                     None if edge_f is None else edge_f.data_ptr(), status.data_ptr(), ws.data_ptr(),
+                                     ws.numel(), torch.cuda.current_stream().cuda_stream)
+        _L.check(rc, "gnn_forward")
+
+    def _partition(self, data, n_total: int, e_total: int):
+        """Contiguous groups of whole graphs, one per stream: [(n0, n1, e0, e1), ...] or None (single stream)."""
+        gs = getattr(data, "graph_sizes", None)
+        parts = int(self.hip_streams)
+        if gs is None or parts < 2 or len(gs[0]) < 2 * parts or sum(gs[0]) != n_total or sum(gs[1]) != e_total:
+            return None
+        nodes, edges = gs
+        out, g0, n0, e0 = [], 0, 0, 0
+        for p in range(parts):
+            g1 = len(nodes) * (p + 1) // parts
+            n1, e1 = n0 + sum(nodes[g0:g1]), e0 + sum(edges[g0:g1])
+            out.append((n0, n1, e0, e1))
+            g0, n0, e0 = g1, n1, e1
+        return out
+
+    @torch.no_grad()
+    def forward(self, data, k=None):
+        x, edge_index = data.x, data.edge_index
+        if not x.is_cuda:
+            raise RuntimeError("PoseNetX_R2 (HIP) needs its inputs on the GPU: call data.to(device) first "
+                               "(there is no CPU fallback)")
+        lib = _L.lib()
+        x = x.view(x.size(0), 3, self.input_img_height, -1)                       # posenet.py:1035
+        self._pack_gnn()
+        fast = self.use_AP and not self.use_attention and k is None and self.knn <= 0 and not self.droprate > 0
+        parts = self._partition(data, x.size(0), edge_index.size(1)) if fast else None
+        if parts is not None and edge_index.dtype == torch.int64 and edge_index.dim() == 2 and edge_index.is_contiguous():
+            return self._forward_streams(lib, x, edge_index, parts)
+        feat = self._enc.run(self.feature_extractor.state_dict, "", x)            # posenet.py:1037
 
         n, d = feat.shape
         if self.use_attention:                                                    # posenet.py:1040-1041
@@ -176,11 +217,6 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         ei = edge_index.contiguous()
         e = ei.size(1)
         dev = feat.device
-        key = (n, e, d, dev)
-        ws = self._gnn_ws.get(key)
-        if ws is None:
-            ws = torch.empty(lib.rpg_gnn_workspace_bytes(n, e, d), dtype=torch.uint8, device=dev)
-            self._gnn_ws = {key: ws}
         abs_pose = torch.empty((n, 6), dtype=torch.float32, device=dev)
         rel_pose = torch.empty((e, 6), dtype=torch.float32, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -188,12 +224,7 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         want_feats = drop or not self.use_AP
         node_f = torch.empty((n, d), dtype=torch.float32, device=dev) if want_feats else None
         edge_f = torch.empty((e, d), dtype=torch.float32, device=dev) if drop else None
-        rc = lib.rpg_gnn_forward_f32(self._gnn_ptrs, len(self._gnn_packed), feat.data_ptr(), ei.data_ptr(), n, e, d,
-                                     int(self.gnn_recursion), abs_pose.data_ptr(), rel_pose.data_ptr(),
-                                     None if node_f is None else node_f.data_ptr(),
-                                     None if edge_f is None else edge_f.data_ptr(), status.data_ptr(), ws.data_ptr(),
-                                     ws.numel(), torch.cuda.current_stream().cuda_stream)
-        _L.check(rc, "gnn_forward")
+        self._gnn_call(lib, feat, ei.data_ptr(), ei.data_ptr() + 8 * e, 0, n, e, abs_pose, rel_pose, node_f, edge_f, status, 0)
 
         # index validation: the reference would raise from aten indexing; check once per edge_index tensor
         ekey = (ei.data_ptr(), e, n, ei._version)
@@ -217,3 +248,36 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
             abs_pose = ops.linear_gather([(node_f, lo), (node_f, hi)], self._extra["heads_pair_w"],
                                          self._extra["heads_pair_b"], e)
         return abs_pose, rel_pose, (edge_index_knn if k is not None else edge_index)
+
+    def _forward_streams(self, lib, x, edge_index, parts):
+        """Fast path (use_AP, no kNN / dropout / extra attention) on ``len(parts)`` concurrent streams."""
+        dev = x.device
+        n_total, e_total = x.size(0), edge_index.size(1)
+        while len(self._streams) < len(parts):
+            self._streams.append(torch.cuda.Stream(device=dev))
+        cur = torch.cuda.current_stream()
+        abs_pose = torch.empty((n_total, 6), dtype=torch.float32, device=dev)
+        rel_pose = torch.empty((e_total, 6), dtype=torch.float32, device=dev)
+        status = torch.zeros(len(parts), dtype=torch.int32, device=dev)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        base = edge_index.data_ptr()
+        for slot, (n0, n1, e0, e1) in enumerate(parts):
+            st = self._streams[slot]
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                feat = self._enc.run(self.feature_extractor.state_dict, "", x[n0:n1], slot=slot)
+                self._gnn_call(lib, feat, base + 8 * e0, base + 8 * (e_total + e0), n0, n1 - n0, e1 - e0, abs_pose[n0:n1],
+                               rel_pose[e0:e1], None, None, status[slot:slot + 1], slot)
+                feat.record_stream(st)
+        for st in self._streams[:len(parts)]:
+            cur.wait_stream(st)
+        ekey = (base, e_total, n_total, edge_index._version)
+        if ekey not in self._checked_edges:
+            bad = int(status.sum().item())
+            if bad:
+                raise IndexError(f"edge_index has {bad} edge(s) with a node id outside its graph group / [0, {n_total})")
+            if len(self._checked_edges) > 64:
+                self._checked_edges.clear()
+            self._checked_edges[ekey] = True
+        return abs_pose, rel_pose, edge_index

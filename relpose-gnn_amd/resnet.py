@@ -51,7 +51,7 @@ class EncoderRunner:
         self._packed, self._ptrs = None, None
         self._ws.clear()
 
-    def run(self, state_dict_fn, prefix: str, x_nchw: torch.Tensor) -> torch.Tensor:
+    def run(self, state_dict_fn, prefix: str, x_nchw: torch.Tensor, slot: int = 0) -> torch.Tensor:
         if not x_nchw.is_cuda:
             raise RuntimeError("the encoder runs on the GPU only (HIP kernels, no CPU fallback); got " + str(x_nchw.device))
         if x_nchw.dtype != torch.float32 or x_nchw.dim() != 4 or x_nchw.shape[1] != 3:
@@ -71,11 +71,12 @@ class EncoderRunner:
         feat_dim = tensors[-2].shape[0]
         planes_c = L.int_array(planes)
         key = (n, h, w, x.device)
-        ws = self._ws.get(key)
-        if ws is None:
+        ent = self._ws.get(slot)          # one workspace per concurrent stream slot, kept for the last shape seen
+        if ent is None or ent[0] != key:
             nbytes = lib.rpg_resnet_workspace_bytes(n, h, w, planes_c)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-            self._ws = {key: ws}          # keep one shape's workspace alive
+            ent = (key, torch.empty(nbytes, dtype=torch.uint8, device=x.device))
+            self._ws[slot] = ent
+        ws = ent[1]
         feat = torch.empty((n, feat_dim), dtype=torch.float32, device=x.device)
         rc = lib.rpg_resnet_forward_f32(self._ptrs, len(tensors), L.int_array(blocks), planes_c, feat_dim, x.data_ptr(),
                                         n, h, w, feat.data_ptr(), ws.data_ptr(), ws.numel(),

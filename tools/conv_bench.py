@@ -63,6 +63,7 @@ def main():
     ops.set_tuning(ops.TUNE_EPILOGUE, args.epi)
     ops.set_tuning(ops.TUNE_TILE, args.tile)
     ops.set_tuning(ops.TUNE_STREAMK, args.sk)
+    ops.set_tuning(ops.TUNE_WINOGRAD, args.wino)
     print(f"# bk={args.bk} epi={args.epi} tile={args.tile} streamk={args.sk}", flush=True)
     for name, n, h, w, cin, cout, k, s, p, res in SHAPES:
         if args.only and args.only not in name:
