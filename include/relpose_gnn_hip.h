@@ -142,7 +142,9 @@ int rpg_scatter_mean_f32(const float* msg, const int32_t* rowptr, const int32_t*
 int rpg_pose_heads_f32(const float* x, const float* w6, const float* b6, int r, int d, float* out, void* stream);
 
 /* Everything after the encoder for use_gnn=True, use_AP=True, knn<=0 (posenet.py:1052-1091).
- * `tensors` HOST array of device pointers, order in params.py.
+ * `tensors` HOST array of device pointers, order in params.py: 22 tensors (reference formulation) or 26 (adds the
+ * node/edge column blocks of proj_edge, edge_mlp.0 and mlp.0 as separate matrices, which lets the node terms be
+ * computed once per node and gathered in the edge GEMM epilogues).
  * feat [n][d], edge rows src[e] / dst[e] with node_offset (see rpg_graph_prepare) -> abs_pose [n][6], rel_pose [e][6].
  * node_out [n][d] / edge_out [e][d]: optional (NULL to skip) copies of the final ReLU'd node and
  * edge features, i.e. the inputs of the heads; the host mirror uses them to apply the reference's
@@ -180,6 +182,8 @@ int rpg_timing_read(double* ms, long long* launches, double* work);
 #define RPG_TUNE_BK 1
 #define RPG_TUNE_EPILOGUE 2
 #define RPG_TUNE_STREAMK 3
+#define RPG_TUNE_GNN_SPLIT 5      /* 1: per-node precompute of the split concatenated-input Linears (default, needs
+                                     the 26-tensor table) | 0: reference formulation (gathered 3-source GEMMs) */
 #define RPG_TUNE_WINOGRAD 4       /* 1: use u_wino43 where given (default) | 0: always the direct kernel */
 int rpg_set_tuning(int key, int value);
 

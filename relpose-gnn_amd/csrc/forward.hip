@@ -151,7 +151,13 @@ namespace {
 enum GnnTensor {
     T_PROJ_W, T_PROJ_B, T_EDGE0_W, T_EDGE0_B, T_EDGE2_W, T_EDGE2_B, T_MSG0_W, T_MSG0_B, T_MSG2_W, T_MSG2_B,
     T_GTP_W, T_GTP_B, T_ATTW_W, T_ATTW_B, T_UPD0_W, T_UPD0_B, T_UPD2_W, T_UPD2_B, T_HEADN_W, T_HEADN_B,
-    T_HEADE_W, T_HEADE_B, T_COUNT
+    T_HEADE_W, T_HEADE_B, T_COUNT,
+    // optional node/edge split of the concatenated-input Linears (enables the per-node precompute path):
+    T_PROJN_W = T_COUNT,   // [2D][D]  = rows cat(proj_edge.W[:, :D], proj_edge.W[:, D:])
+    T_NODE3_W,             // [3D][D]  = rows cat(edge_mlp.0.W[:, :D], edge_mlp.0.W[:, D:2D], mlp.0.W[:, :D])
+    T_EDGE0E_W,            // [D][D]   = edge_mlp.0.W[:, 2D:]
+    T_MSG0E_W,             // [D][D]   = mlp.0.W[:, D:]
+    T_COUNT_SPLIT
 };
 
 struct GnnPlan {
@@ -168,6 +174,7 @@ size_t gnn_bytes(int n, int e, int d) {
     b += align_up((size_t)e * 3 * c * 4, 256);             // g|theta|phi
     b += align_up((size_t)e * c * 4, 256);                 // y
     b += 4 * align_up((size_t)n * d * 4, 256);             // agg, node hidden, x ping-pong
+    b += align_up((size_t)n * 3 * d * 4, 256);             // per-node partial products of the split Linears
     return b;
 }
 }  // namespace
@@ -181,12 +188,13 @@ extern "C" int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, c
                                    const int64_t* edst, int64_t node_offset, int n, int e, int d, int gnn_recursion, float* abs_pose,
                                    float* rel_pose, float* node_out, float* edge_out, int32_t* status, void* workspace,
                                    size_t workspace_bytes, void* stream) {
-    if (!tensors || n_tensors != T_COUNT || !feat || !esrc || !edst || !abs_pose || !rel_pose || !status || !workspace ||
+    if (!tensors || (n_tensors != T_COUNT && n_tensors != T_COUNT_SPLIT) || !feat || !esrc || !edst || !abs_pose || !rel_pose || !status || !workspace ||
         n <= 0 || e <= 0 || d <= 0 || (d & 31) || gnn_recursion < 0)
         return RPG_ERR_BAD_ARG;
-    for (int i = 0; i < T_COUNT; ++i)
+    for (int i = 0; i < n_tensors; ++i)
         if (!tensors[i]) return RPG_ERR_BAD_ARG;
     if (workspace_bytes < gnn_bytes(n, e, d)) return RPG_ERR_WORKSPACE;
+    const bool split = (n_tensors == T_COUNT_SPLIT) && rpg::gnn_split_enabled();
     hipStream_t s = rpg::as_stream(stream);
     const int c = d / 8;
 
@@ -204,6 +212,7 @@ extern "C" int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, c
     float* agg = cv.take<float>((size_t)n * d);
     float* nhid = cv.take<float>((size_t)n * d);
     float* xbuf[2] = {cv.take<float>((size_t)n * d), cv.take<float>((size_t)n * d)};
+    float* node3 = cv.take<float>((size_t)n * 3 * d);
 
     int rc;
     if ((rc = rpg_graph_prepare(esrc, edst, node_offset, e, n, ends, rowptr, cursor, perm, status, stream)) != RPG_OK) return rc;
@@ -223,19 +232,48 @@ extern "C" int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, c
         return rpg::launch_linear(g, tensors[wt], tensors[wt + 1], residual, out, m, n_out, relu, s);
     };
 
+    // A Linear fed by cat[x[a], x[b], e] splits as W_a x[a] + W_b x[b] + W_e e: the node terms are computed once per
+    // NODE (n rows) and added as gathered rows in the edge GEMM's epilogue (summation order changes only).
+    auto node_gemm = [&](const float* xin, int wt, int n_out) {
+        rpg::GatherSrc g{};
+        g.n = 1; g.a[0] = xin; g.idx[0] = nullptr; g.ld[0] = d; g.width[0] = d;
+        return rpg::launch_linear(g, tensors[wt], nullptr, nullptr, node3, n, n_out, 0, s);
+    };
+    auto edge_gemm = [&](const float* ein, int wt, int bias_t, const float* r1, const int64_t* i1, const float* r2,
+                         const int64_t* i2, float* out) {
+        rpg::GatherSrc g{};
+        g.n = 1; g.a[0] = ein; g.idx[0] = nullptr; g.ld[0] = d; g.width[0] = d;
+        const rpg::GatherRes gr{r1, i1, r2, i2, 3 * d};
+        return rpg::launch_linear(g, tensors[wt], tensors[bias_t], nullptr, out, e, d, 1, s, &gr);
+    };
+
     // edge_feat = relu(proj_edge(cat[x[min], x[max]]))                                   posenet.py:1053-1055
     const float* x = feat;
     float* ecur = ebuf[0];
-    if ((rc = linear(2, x, lo, d, x, hi, d, nullptr, nullptr, 0, T_PROJ_W, nullptr, ecur, e, d, 1)) != RPG_OK) return rc;
+    if (split) {
+        if ((rc = node_gemm(x, T_PROJN_W, 2 * d)) != RPG_OK) return rc;                  // [n][2d] = [W_lo x | W_hi x]
+        if ((rc = rpg::launch_gather_add2_relu(node3, lo, hi, tensors[T_PROJ_B], ecur, e, d, s)) != RPG_OK) return rc;
+    } else if ((rc = linear(2, x, lo, d, x, hi, d, nullptr, nullptr, 0, T_PROJ_W, nullptr, ecur, e, d, 1)) != RPG_OK) {
+        return rc;
+    }
 
     for (int r = 0; r < gnn_recursion; ++r) {                                           // posenet.py:1061-1069
         float* enew = (ecur == ebuf[0]) ? ebuf[1] : ebuf[0];
         float* xnew = xbuf[r & 1];
         // edge update: edge_mlp(cat[x[src], x[dst], e])                                 my_gnn_layer.py:296-297
-        if ((rc = linear(3, x, src, d, x, dst, d, ecur, nullptr, d, T_EDGE0_W, nullptr, hid, e, d, 1)) != RPG_OK) return rc;
+        if (split) {
+            if ((rc = node_gemm(x, T_NODE3_W, 3 * d)) != RPG_OK) return rc;              // [n][3d] = [Ws x | Wd x | Wm x]
+            if ((rc = edge_gemm(ecur, T_EDGE0E_W, T_EDGE0_B, node3, src, node3 + d, dst, hid)) != RPG_OK) return rc;
+        } else if ((rc = linear(3, x, src, d, x, dst, d, ecur, nullptr, d, T_EDGE0_W, nullptr, hid, e, d, 1)) != RPG_OK) {
+            return rc;
+        }
         if ((rc = linear(1, hid, nullptr, d, nullptr, nullptr, 0, nullptr, nullptr, 0, T_EDGE2_W, nullptr, enew, e, d, 0)) != RPG_OK) return rc;
         // message: mlp(cat[x[src], e_new]) then AttentionBlock                          my_gnn_layer.py:304-307
-        if ((rc = linear(2, x, src, d, enew, nullptr, d, nullptr, nullptr, 0, T_MSG0_W, nullptr, hid, e, d, 1)) != RPG_OK) return rc;
+        if (split) {
+            if ((rc = edge_gemm(enew, T_MSG0E_W, T_MSG0_B, node3 + 2 * d, src, nullptr, nullptr, hid)) != RPG_OK) return rc;
+        } else if ((rc = linear(2, x, src, d, enew, nullptr, d, nullptr, nullptr, 0, T_MSG0_W, nullptr, hid, e, d, 1)) != RPG_OK) {
+            return rc;
+        }
         if ((rc = linear(1, hid, nullptr, d, nullptr, nullptr, 0, nullptr, nullptr, 0, T_MSG2_W, nullptr, msg, e, d, 0)) != RPG_OK) return rc;
         if ((rc = linear(1, msg, nullptr, d, nullptr, nullptr, 0, nullptr, nullptr, 0, T_GTP_W, nullptr, gtp, e, 3 * c, 0)) != RPG_OK) return rc;
         if ((rc = rpg_attention_rows_f32(gtp, e, c, yat, stream)) != RPG_OK) return rc;

@@ -30,11 +30,20 @@ constexpr int NTHREADS = 256;
 struct Epilogue {
     const float* scale;      // per output column, or null
     const float* shift;      // per output column (bias / folded BN shift), or null
-    const float* residual;   // [M][ldc] or null
+    const float* residual;   // [M][ldc] or null; row m reads row res_idx[m] (pitch ldr) when res_idx is given
     float* out;              // [M][ldc]
     int ldc;
     int relu;
+    const int64_t* res_idx = nullptr;     // gather index of `residual` rows, or null (= row m, pitch ldc)
+    const float* residual2 = nullptr;     // second gathered residual (pitch ldr), or null
+    const int64_t* res2_idx = nullptr;
+    int ldr = 0;                          // pitch of gathered residual rows
 };
+
+// byte-free helpers: element offset of row m's residual(s)
+__device__ __forceinline__ size_t res_off(const Epilogue& ep, int m) {
+    return ep.res_idx ? (size_t)ep.res_idx[m] * ep.ldr : (size_t)m * ep.ldc;
+}
 
 __device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -286,8 +295,13 @@ __device__ __forceinline__ void tile_epilogue(float* lds, const Epilogue& ep, in
                 const int row = r_in + RPI * t;
                 v[t] = *reinterpret_cast<const float4*>(&slab[row * EP + 4 * c4]);
                 rs[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ep.residual && n_ok && (mb + row) < M)
-                    rs[t] = *reinterpret_cast<const float4*>(ep.residual + (size_t)(mb + row) * ep.ldc + nb);
+                if (ep.residual && n_ok && (mb + row) < M) {
+                    rs[t] = *reinterpret_cast<const float4*>(ep.residual + res_off(ep, mb + row) + nb);
+                    if (ep.residual2) {
+                        const float4 r2 = *reinterpret_cast<const float4*>(ep.residual2 + (size_t)ep.res2_idx[mb + row] * ep.ldr + nb);
+                        rs[t].x += r2.x; rs[t].y += r2.y; rs[t].z += r2.z; rs[t].w += r2.w;
+                    }
+                }
             }
 #pragma unroll
             for (int t = 0; t < NIT; ++t) {
@@ -319,7 +333,10 @@ __device__ __forceinline__ void tile_epilogue(float* lds, const Epilogue& ep, in
                     if (m < M) {
                         float v = acc[i][j][e] * sc + sh;
                         const size_t o = (size_t)m * ep.ldc + n;
-                        if (ep.residual) v += ep.residual[o];
+                        if (ep.residual) {
+                            v += ep.residual[res_off(ep, m) + n];
+                            if (ep.residual2) v += ep.residual2[(size_t)ep.res2_idx[m] * ep.ldr + n];
+                        }
                         if (ep.relu) v = fmaxf(v, 0.f);
                         ep.out[o] = v;
                     }
@@ -420,7 +437,13 @@ __global__ __launch_bounds__(NTHREADS) void streamk_fixup_kernel(const float* __
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f), rs = sh;
         if (ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + n);
         if (ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + n);
-        if (ep.residual) rs = *reinterpret_cast<const float4*>(ep.residual + o);
+        if (ep.residual) {
+            rs = *reinterpret_cast<const float4*>(ep.residual + res_off(ep, m) + n);
+            if (ep.residual2) {
+                const float4 r2 = *reinterpret_cast<const float4*>(ep.residual2 + (size_t)ep.res2_idx[m] * ep.ldr + n);
+                rs.x += r2.x; rs.y += r2.y; rs.z += r2.z; rs.w += r2.w;
+            }
+        }
         float4 v;
         v.x = s.x * sc.x + sh.x + rs.x; v.y = s.y * sc.y + sh.y + rs.y;
         v.z = s.z * sc.z + sh.z + rs.z; v.w = s.w * sc.w + sh.w + rs.w;
@@ -430,7 +453,10 @@ __global__ __launch_bounds__(NTHREADS) void streamk_fixup_kernel(const float* __
         const float sv[4] = {s.x, s.y, s.z, s.w};
         for (int c = 0; c < 4 && n + c < N; ++c) {
             float v = sv[c] * (ep.scale ? ep.scale[n + c] : 1.f) + (ep.shift ? ep.shift[n + c] : 0.f);
-            if (ep.residual) v += ep.residual[o + c];
+            if (ep.residual) {
+                v += ep.residual[res_off(ep, m) + n + c];
+                if (ep.residual2) v += ep.residual2[(size_t)ep.res2_idx[m] * ep.ldr + n + c];
+            }
             if (ep.relu) v = fmaxf(v, 0.f);
             ep.out[o + c] = v;
         }
@@ -444,6 +470,7 @@ int g_force_tile = -1;
 int g_bk = 0;                        // 0 = automatic: 32 for the 128x128 tile (2 workgroups/CU), else 16
 int g_epi_lds = 1;
 int g_streamk = 1;
+int g_gnn_split = 1;
 constexpr int SK_MIN_ITS = 8;        // at least this many k-steps per stream-K workgroup
 constexpr int SK_MIN_NK = 32;        // tiles with fewer k-steps are not worth splitting (fix-up traffic dominates)
 
@@ -549,7 +576,8 @@ int launch_tiles(const Args& args, const float* Wt, int ldw, int M, int N, int K
     const int bk = g_bk ? g_bk : ((t == TILE_128x128 && K >= 256) ? 32 : 16);
     // 16-byte epilogue accesses need 4-column groups: N % 4 == 0 and 16-byte aligned rows
     const bool vec_ok = (N % 4 == 0) && (ep.ldc % 4 == 0) && rpg::aligned16(ep.out) &&
-                        (!ep.residual || rpg::aligned16(ep.residual)) && (!ep.scale || rpg::aligned16(ep.scale)) &&
+                        (!ep.residual || rpg::aligned16(ep.residual)) && (!ep.residual2 || rpg::aligned16(ep.residual2)) &&
+                        (ep.ldr % 4 == 0) && (!ep.scale || rpg::aligned16(ep.scale)) &&
                         (!ep.shift || rpg::aligned16(ep.shift));
     const bool epi = g_epi_lds && vec_ok;
     if (bk == 32) {
@@ -565,6 +593,8 @@ int launch_tiles(const Args& args, const float* Wt, int ldw, int M, int N, int K
 }  // namespace
 
 namespace rpg {
+
+bool gnn_split_enabled() { return g_gnn_split != 0; }
 
 int launch_conv(const float* x, const float* w, const float* scale, const float* shift, const float* residual,
                 float* y, int n, int h, int wd, int cin, int cout, int kh, int kw, int stride, int pad, int relu,
@@ -587,7 +617,7 @@ int launch_conv(const float* x, const float* w, const float* scale, const float*
 }
 
 int launch_linear(const GatherSrc& src, const float* weight, const float* bias, const float* residual, float* out,
-                  int m, int n_out, int relu, hipStream_t s) {
+                  int m, int n_out, int relu, hipStream_t s, const GatherRes* gres) {
     if (src.n < 1 || src.n > 3 || !weight || !out || m <= 0 || n_out <= 0 || !aligned16(weight)) return RPG_ERR_BAD_ARG;
     GatherArgs a{};
     int K = 0;
@@ -606,6 +636,12 @@ int launch_linear(const GatherSrc& src, const float* weight, const float* bias, 
     a.w01 = src.n >= 2 ? src.width[0] + src.width[1] : K;
     a.K = K;
     Epilogue ep{nullptr, bias, residual, out, n_out, relu};
+    if (gres) {
+        if (!gres->res1 || !gres->idx1 || gres->ld < n_out || (gres->res2 && !gres->idx2)) return RPG_ERR_BAD_ARG;
+        ep.residual = gres->res1; ep.res_idx = gres->idx1;
+        ep.residual2 = gres->res2; ep.res2_idx = gres->idx2;
+        ep.ldr = gres->ld;
+    }
     const int slot = timing_begin(RPG_TIMER_LINEAR, s);
     launch_tiles<GatherLoader, GatherArgs>(a, weight, K, m, n_out, K, ep, s);
     timing_end(slot, 2.0 * (double)m * n_out * (double)K, s);
@@ -643,6 +679,7 @@ extern "C" int rpg_set_tuning(int key, int value) {
         case RPG_TUNE_BK: if (value != 0 && value != 16 && value != 32) return RPG_ERR_BAD_ARG; g_bk = value; return RPG_OK;
         case RPG_TUNE_EPILOGUE: g_epi_lds = value != 0; return RPG_OK;
         case RPG_TUNE_STREAMK: g_streamk = value != 0; return RPG_OK;
+        case RPG_TUNE_GNN_SPLIT: g_gnn_split = value != 0; return RPG_OK;
         case RPG_TUNE_WINOGRAD: rpg::wino_set(value != 0); return RPG_OK;
         default: return RPG_ERR_BAD_ARG;
     }

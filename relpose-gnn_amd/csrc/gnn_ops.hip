@@ -105,6 +105,24 @@ __global__ __launch_bounds__(NT) void edge_concat_kernel(const float4* __restric
     }
 }
 
+// out[e] = relu(pq[lo[e]][0:d] + pq[hi[e]][d:2d] + bias): proj_edge after splitting its weight into the two node
+// halves (W [x_lo, x_hi] = W_lo x_lo + W_hi x_hi, each product computed once per NODE instead of once per edge).
+__global__ __launch_bounds__(NT) void gather_add2_relu_kernel(const float4* __restrict__ pq, const int64_t* __restrict__ lo,
+                                                              const int64_t* __restrict__ hi, const float4* __restrict__ bias,
+                                                              float4* __restrict__ out, int d4, long total) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % d4);
+        const long e = i / d4;
+        const float4 a = pq[(size_t)lo[e] * (2 * d4) + c];
+        const float4 b = pq[(size_t)hi[e] * (2 * d4) + d4 + c];
+        const float4 bb = bias[c];
+        float4 v;
+        v.x = fmaxf(a.x + b.x + bb.x, 0.f); v.y = fmaxf(a.y + b.y + bb.y, 0.f);
+        v.z = fmaxf(a.z + b.z + bb.z, 0.f); v.w = fmaxf(a.w + b.w + bb.w, 0.f);
+        out[i] = v;
+    }
+}
+
 __global__ __launch_bounds__(NT) void relu_inplace_kernel(float4* __restrict__ x, long total) {
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         float4 v = x[i];
@@ -152,8 +170,8 @@ __global__ __launch_bounds__(NT) void attention_rows_kernel(const float* __restr
             const float4 g = *reinterpret_cast<const float4*>(&s_g[j]);
             // product and subtraction rounded separately (no FMA contraction), as the reference's
             // matmul-then-softmax does, so the arg-max term is exactly exp(0)
-            const float p0 = expf(__fsub_rn(__fmul_rn(phi, th.x), m)), p1 = expf(__fsub_rn(__fmul_rn(phi, th.y), m));
-            const float p2 = expf(__fsub_rn(__fmul_rn(phi, th.z), m)), p3 = expf(__fsub_rn(__fmul_rn(phi, th.w), m));
+            const float p0 = __expf(__fsub_rn(__fmul_rn(phi, th.x), m)), p1 = __expf(__fsub_rn(__fmul_rn(phi, th.y), m));
+            const float p2 = __expf(__fsub_rn(__fmul_rn(phi, th.z), m)), p3 = __expf(__fsub_rn(__fmul_rn(phi, th.w), m));
             den += p0; num += p0 * g.x;
             den += p1; num += p1 * g.y;
             den += p2; num += p2 * g.z;
@@ -335,6 +353,15 @@ inline int capped_grid(long items) {
 }  // namespace
 
 namespace rpg {
+int launch_gather_add2_relu(const float* pq, const int64_t* lo, const int64_t* hi, const float* bias, float* out, int e,
+                            int d, hipStream_t s) {
+    if (!pq || !lo || !hi || !bias || !out || e <= 0 || d <= 0 || (d & 3)) return RPG_ERR_BAD_ARG;
+    const long total = (long)e * (d / 4);
+    hipLaunchKernelGGL(gather_add2_relu_kernel, dim3(capped_grid(total)), dim3(NT), 0, s, reinterpret_cast<const float4*>(pq),
+                       lo, hi, reinterpret_cast<const float4*>(bias), reinterpret_cast<float4*>(out), d / 4, total);
+    RPG_CHECK_LAUNCH("gather_add2_relu");
+    return RPG_OK;
+}
 int launch_relu_inplace(float* x, long n_floats, hipStream_t s) {
     if (!x || n_floats <= 0 || (n_floats & 3)) return RPG_ERR_BAD_ARG;
     hipLaunchKernelGGL(relu_inplace_kernel, dim3(capped_grid(n_floats / 4)), dim3(NT), 0, s,

@@ -44,7 +44,18 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
                      float* y, int n, int h, int w, int cin, int cout, int relu, hipStream_t s);
 bool wino_enabled();
 void wino_set(int on);
+// Gathered residual rows added in the epilogue: out[m] += res1[idx1[m]] (+ res2[idx2[m]]), row pitch ld.
+struct GatherRes {
+    const float* res1;
+    const int64_t* idx1;
+    const float* res2;
+    const int64_t* idx2;
+    int ld;
+};
 int launch_linear(const GatherSrc& src, const float* weight, const float* bias, const float* residual, float* out,
-                  int m, int n_out, int relu, hipStream_t s);
+                  int m, int n_out, int relu, hipStream_t s, const GatherRes* gres = nullptr);
+int launch_gather_add2_relu(const float* pq, const int64_t* lo, const int64_t* hi, const float* bias, float* out, int e,
+                            int d, hipStream_t s);
+bool gnn_split_enabled();
 
 }  // namespace rpg

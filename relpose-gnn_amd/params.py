@@ -12,7 +12,7 @@ encoder (``rpg_resnet_forward_f32`` tensor order)
         u       [6][Cout][3][Cin]     = Winograd F(4,3) weights of a 3x3 stride-1 convolution, or None
     then fc.weight [feat][512], fc.bias [feat]
 
-GNN (``rpg_gnn_forward_f32`` tensor order, 22 tensors)
+GNN (``rpg_gnn_forward_f32`` tensor order, 22 tensors + 4 optional split matrices, see pack_gnn)
     proj_edge.{weight,bias}; gnn1.edge_model.edge_mlp.{0,2}.{weight,bias}; gnn1.mlp.{0,2}.{weight,bias};
     att g|theta|phi weights concatenated to [3C][D] and biases to [3C]; gnn1.att.W.{weight,bias};
     gnn1.mlp_updating.{0,2}.{weight,bias}; node heads cat(fc_xyz, fc_wpqr) -> [6][D],[6];
@@ -114,4 +114,15 @@ def pack_gnn(sd: Dict[str, torch.Tensor], gnn: str = "gnn1.") -> List[torch.Tens
     t += lin(gnn + "mlp_updating.0") + lin(gnn + "mlp_updating.2")
     t += cat(["fc_xyz", "fc_wpqr"])
     t += cat(["fc_xyz_R", "fc_wpqr_R"])
+    # column blocks of the concatenated-input Linears as separate row-major matrices (slots 22..25): lets the node terms
+    # W_a x[a] be computed once per node and gathered, instead of once per edge
+    wp = sd["proj_edge.weight"].float()
+    we = sd[gnn + "edge_model.edge_mlp.0.weight"].float()
+    wm = sd[gnn + "mlp.0.weight"].float()
+    d = wp.shape[1] // 2
+    if we.shape[1] == 3 * d and wm.shape[1] == 2 * d and wp.shape[0] == d:
+        t.append(torch.cat([wp[:, :d], wp[:, d:]], 0).contiguous())                       # [2D][D]
+        t.append(torch.cat([we[:, :d], we[:, d:2 * d], wm[:, :d]], 0).contiguous())       # [3D][D]
+        t.append(we[:, 2 * d:].contiguous())                                              # [D][D]
+        t.append(wm[:, d:].contiguous())                                                  # [D][D]
     return t

@@ -263,3 +263,27 @@ def test_multi_stream_equals_single_stream(dev):
     bad.edge_index[0, -1] = 0                      # last graph's edge pointing into the first graph
     with pytest.raises(IndexError):
         m(bad)
+
+
+def test_gnn_node_split_equals_reference_formulation(dev, golden_dir):
+    """Per-node precompute of the split Linears (default) vs the reference formulation (3-source gathered GEMMs): same
+    poses up to fp32 summation order, at D=64 against golden G4 and at the R3 width against each other."""
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd import ops
+    g = np.load(os.path.join(golden_dir, "g4_full_small.npz"))
+    m, _ = _build(64, 32, (8, 16, 32, 64), (1, 1, 1, 1), dev)
+    d = _data(S.synth_images(16, 32, 40, seed=3), 8, dev)
+    big, _ = _build(2048, 64, (64, 128, 256, 512), (3, 4, 6, 3), dev)
+    db = _data(S.synth_images(8 * 6, 64, 64, seed=21), 8, dev)
+    outs = {}
+    try:
+        for split in (1, 0):
+            ops.set_tuning(ops.TUNE_GNN_SPLIT, split)
+            a, r, _ = m(d)
+            assert rel_err(a.cpu(), g["abs"]) < TOL and rel_err(r.cpu(), g["rel"]) < TOL
+            outs[split] = tuple(t.cpu() for t in big(db)[:2])
+    finally:
+        ops.set_tuning(ops.TUNE_GNN_SPLIT, 1)
+    ea, er = rel_err(outs[1][0], outs[0][0]), rel_err(outs[1][1], outs[0][1])
+    _report("gnn_node_split_vs_reference_formulation_R3_64px", ea, er)
+    assert ea < TOL and er < TOL

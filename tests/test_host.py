@@ -74,7 +74,9 @@ def test_weight_packing():
     ref = O._bn(sd, "feature_extractor.bn1.", x)
     assert torch.allclose(x * t[1].view(1, -1, 1, 1) + t[2].view(1, -1, 1, 1), ref, atol=1e-6)
     g = pack_gnn(sd)
-    assert len(g) == 22 and g[10].shape == (24, 64) and g[18].shape == (6, 64) and g[21].shape == (6,)
+    assert len(g) == 26 and g[22].shape == (128, 64) and g[23].shape == (192, 64) and g[24].shape == (64, 64)
+    assert torch.equal(g[23][128:], sd["gnn1.mlp.0.weight"][:, :64]) and torch.equal(g[25], sd["gnn1.mlp.0.weight"][:, 64:])
+    assert g[10].shape == (24, 64) and g[18].shape == (6, 64) and g[21].shape == (6,)
     assert torch.equal(g[10][8:16], sd["gnn1.att.theta.weight"]) and torch.equal(g[20][3:], sd["fc_wpqr_R.weight"])
     bad = dict(sd)
     bad.pop("feature_extractor.layer2.0.downsample.0.weight")
