@@ -165,16 +165,24 @@ def main():
                        "image": [IMG, IMG], "streams_per_gpu": args.streams,
                        "parallelism": f"graph-sharded x{world}, all-gather of rel poses per step"},
         }
-        if kt is not None and kt["conv"]["launches"]:
-            c = kt["conv"]
+        if kt is not None and kt["conv_wino"]["launches"]:
+            c = kt["conv_wino"]
             ach = c["work"] / (c["ms"] * 1e-3) / 1e12
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic_wino43.json")
+            if os.path.exists(tpath):          # PMC counters cannot be read from inside the process: committed profile
+                with open(tpath) as f:
+                    tj = json.load(f)
+                traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/r1_pmc_traffic_wino43.json (rocprofv3 --pmc, corrected)"
             line["roofline"] = {
                 "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
-                "kernel": "conv+BN(+residual)+ReLU on v_mfma_f32_32x32x2_f32: wino43_conv_kernel (30 3x3/s1 layers) + "
-                          "gemm_tile/streamk kernels<ConvLoader> (stem, 3 strided 3x3, 3 1x1)",
+                "frac": round(ach / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "wino43_conv_kernel (3x3/stride-1 conv + BN (+residual) + ReLU as 1-D Winograd F(4,3) on "
+                          "v_mfma_f32_32x32x2_f32; 29 of the 36 ResNet34 convolutions)",
                 "launches": c["launches"], "avg_launch_ms": round(c["ms"] / c["launches"], 4),
                 "alg_gflop_per_launch": round(c["work"] / c["launches"] / 1e9, 3),
+                "note": "achieved = ALGORITHMIC (direct-convolution) FLOP / duration; F(4,3) executes ~0.5-0.57x of them "
+                        "on the matrix pipe, so the pipe itself is ~55 % busy (PMC SQ_VALU_MFMA_BUSY_CYCLES, see DESIGN.md)",
                 "share_of_instrumented_step_time": round(c["ms"] / (1e3 * elapsed_ev), 4),
                 "measured_on": f"{args.steps} further steps of the same workload, one stream, per-launch HIP events: "
                                f"{round(1e3 * elapsed_ev / args.steps, 3)} ms/step, vs "
@@ -182,7 +190,7 @@ def main():
                                f"({args.streams} concurrent streams, no events)",
             }
             other = {}
-            for k in ("linear", "attention", "scatter"):
+            for k in ("conv", "linear", "attention", "scatter"):
                 v = kt[k]
                 if not v["launches"]:
                     continue
@@ -196,6 +204,7 @@ def main():
                     other[k] = {"achieved": round(tf, 2), "unit": "TFLOP/s", "launches": v["launches"],
                                 "avg_launch_ms": round(v["ms"] / v["launches"], 5),
                                 "share_of_instrumented_step_time": round(v["ms"] / (1e3 * elapsed_ev), 4)}
+            other["conv"]["kernel"] = "direct implicit-GEMM conv (stem 7x7/2, three 3x3/2, three 1x1/2)"
             line["other_kernels"] = other
         if world == 1 and args.cpu_baseline_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(sd, args.cpu_baseline_seconds)

@@ -160,11 +160,12 @@ int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, const float*
 /* ------------------------------------------------------------------------------------------- */
 /* Per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline).  */
 /* ------------------------------------------------------------------------------------------- */
-#define RPG_TIMER_CONV 0          /* implicit-GEMM convolutions                                    */
+#define RPG_TIMER_CONV 0          /* direct implicit-GEMM convolutions (stem, strided 3x3, 1x1)     */
 #define RPG_TIMER_LINEAR 1        /* gathered Linear GEMMs                                         */
 #define RPG_TIMER_SCATTER 2       /* scatter-mean                                                  */
 #define RPG_TIMER_ATTENTION 3     /* attention rows                                                */
-#define RPG_TIMER_COUNT 4
+#define RPG_TIMER_CONV_WINO 4     /* Winograd F(4,3) 3x3/stride-1 convolutions (work = direct-conv FLOP) */
+#define RPG_TIMER_COUNT 5
 /* enable != 0: every launch of the listed kernel classes is bracketed by hipEventRecord. */
 int rpg_timing_enable(int enable);
 /* Synchronises, sums the elapsed time of all bracketed launches since the last read.

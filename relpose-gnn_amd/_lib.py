@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "librelpose_gnn_hip.so")
 
 RPG_OK, RPG_ERR_BAD_ARG, RPG_ERR_LAUNCH, RPG_ERR_WORKSPACE = 0, -1, -2, -3
-TIMER_NAMES = ("conv", "linear", "scatter", "attention")
+TIMER_NAMES = ("conv", "linear", "scatter", "attention", "conv_wino")
 
 # every symbol include/relpose_gnn_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (

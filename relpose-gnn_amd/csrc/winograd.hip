@@ -3,7 +3,7 @@
 // Why: the f32 matrix pipe (v_mfma_f32_32x32x2_f32) is the roofline of the ResNet34 encoder; F(4,3) produces 4 output
 // pixels of a row from 6 input pixels with 6 multiplies per (kernel row, channel) instead of 12, i.e. HALF the MFMA
 // work, and stays pure fp32 (the transforms are small fp32 linear combinations; measured error ~2e-6 per layer).
-// 30 of the 36 convolutions of ResNet34 (all 3x3 stride-1 ones) take this path.
+// 29 of the 36 convolutions of ResNet34 (all 3x3 stride-1 ones) take this path.
 //
 //   y[4t+i] = sum_xi AT[i][xi] * M[xi],   M[xi][tile][cout] = sum_{kh,c} V[xi][tile][kh,c] * U[xi][cout][kh,c]
 //   V[xi] = sum_j BT[xi][j] * d[j]   (d = the 6 input pixels 4t-1 .. 4t+4 of row ho+kh-1, zero outside the image)
@@ -284,7 +284,7 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
     }
     const int tm = (int)((M + BMT - 1) / BMT), tn = (cout + BN - 1) / BN;
     Epi ep{scale, shift, residual, y, relu};
-    const int slot = timing_begin(RPG_TIMER_CONV, s);
+    const int slot = timing_begin(RPG_TIMER_CONV_WINO, s);
     hipLaunchKernelGGL(wino43_conv_kernel, dim3(tm * tn), dim3(NT), LDS_BYTES, s, x, u, h, w, cin, cout, tw, (int)M, ep, tn);
     timing_end(slot, 2.0 * (double)n * h * w * cout * 9.0 * cin, s);      // algorithmic (direct-convolution) FLOP
     RPG_CHECK_LAUNCH("conv3x3_wino43");
