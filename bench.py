@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU the batch is spread over in the timed region")
+    ap.add_argument("--encoder-dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32 = the headline configuration (configs[1]); bf16 = configs[2] (bf16 activations + MFMA conv)")
     return ap.parse_args()
 
 
@@ -101,6 +103,7 @@ def main():
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     model.hip_streams = args.streams
+    model.encoder_dtype = args.encoder_dtype
 
     B = args.graphs
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -146,6 +149,7 @@ def main():
         ops.timing_enable(False)
         kt = ops.timing_read()
         model.hip_streams = args.streams
+    model.encoder_dtype = args.encoder_dtype
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -158,14 +162,22 @@ def main():
             "metric": "graphs/sec (8-node fully-connected, 224x224)", "value": round(graphs / elapsed, 2),
             "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: batch=32 8-node fully-connected graphs per GPU, 224x224 RGB, "
+            "vs_baseline": None, "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder (f32 accumulate) + f32 GNN",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: batch={B} 8-node fully-connected graphs per GPU, 224x224 RGB, "
                                    "fp32, ResNet34 + GNN (D=2048, gnn_recursion=2, droprate=0, eval), random-init weights",
                        "graphs_per_step_per_gpu": B, "nodes_per_graph": NODES, "edges_per_graph": NODES * (NODES - 1),
                        "image": [IMG, IMG], "streams_per_gpu": args.streams,
                        "parallelism": f"graph-sharded x{world}, all-gather of rel poses per step"},
         }
-        if kt is not None and kt["conv_wino"]["launches"]:
+        if kt is not None and args.encoder_dtype == "bf16" and kt["conv"]["launches"]:
+            c = kt["conv"]
+            line["config"]["workload"] = line["config"]["workload"].replace("configs[1]", "configs[2]").replace(", fp32,", ", bf16 encoder,")
+            line["roofline"] = {"bound": "hbm", "kernel": "conv_bf16_kernel (implicit-GEMM conv, v_mfma_f32_32x32x16_bf16)",
+                                "achieved_tflops": round(c["work"] / (c["ms"] * 1e-3) / 1e12, 2), "launches": c["launches"],
+                                "avg_launch_ms": round(c["ms"] / c["launches"], 4), "traffic": None,
+                                "note": "bf16 matrix peak is 2.5 PFLOP/s: these convolutions are memory/latency-bound"}
+        elif kt is not None and kt["conv_wino"]["launches"]:
             c = kt["conv_wino"]
             ach = c["work"] / (c["ms"] * 1e-3) / 1e12
             traffic, traffic_src = None, None

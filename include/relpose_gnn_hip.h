@@ -84,6 +84,19 @@ int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors, const int
                            int feat_dim, const float* x_nchw, int n, int h, int w, float* feat,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* bf16 encoder (BASELINE.json configs[2]: bf16 activations + bf16 MFMA convolutions, fp32 accumulate / BN epilogue).
+ *   rpg_conv2d_bn_act_nhwc_bf16: x, w_ohwi, residual, y are bf16 (y is fp32 when out_f32 != 0); scale/shift fp32;
+ *                                cin % 8 == 0, cout % 4 == 0; other arguments as rpg_conv2d_bn_act_nhwc_f32.
+ *   rpg_resnet_forward_bf16:     tensors = per conv {w_ohwi bf16 (stem Cin padded 3 -> 8), scale f32, shift f32}, then
+ *                                fc weight bf16 [feat][512], fc bias f32; x_nchw fp32 -> feat fp32 [n][feat_dim].      */
+int rpg_conv2d_bn_act_nhwc_bf16(const void* x, const void* w_ohwi, const float* scale, const float* shift,
+                                const void* residual, void* y, int n, int h, int w, int cin, int cout, int kh, int kw,
+                                int stride, int pad, int relu, int out_f32, void* stream);
+size_t rpg_resnet_bf16_workspace_bytes(int n, int h, int w, const int* planes);
+int rpg_resnet_forward_bf16(const void* const* tensors, int n_tensors, const int* blocks, const int* planes, int feat_dim,
+                            const float* x_nchw, int n, int h, int w, float* feat, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------- */
 /* GNN primitives                                                                                */
 /* ------------------------------------------------------------------------------------------- */

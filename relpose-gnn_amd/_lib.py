@@ -22,7 +22,8 @@ SYMBOLS = (
     "rpg_resnet_forward_f32", "rpg_graph_prepare", "rpg_edge_concat_gather_f32", "rpg_linear_gather_f32",
     "rpg_attention_rows_f32", "rpg_scatter_mean_f32", "rpg_pose_heads_f32", "rpg_gnn_workspace_bytes",
     "rpg_gnn_forward_f32", "rpg_timing_enable", "rpg_timing_read", "rpg_set_tuning", "rpg_knn_graph_f32", "rpg_wino43_transform_weights_f32",
-    "rpg_conv3x3_wino43_bn_act_nhwc_f32",
+    "rpg_conv3x3_wino43_bn_act_nhwc_f32", "rpg_conv2d_bn_act_nhwc_bf16", "rpg_resnet_bf16_workspace_bytes",
+    "rpg_resnet_forward_bf16",
 )
 
 
@@ -62,6 +63,11 @@ def _declare(lib: C.CDLL) -> None:
                                         _vp, _vp, _sz, _vp]
     lib.rpg_timing_enable.argtypes = [_i]
     lib.rpg_set_tuning.argtypes = [_i, _i]
+    lib.rpg_conv2d_bn_act_nhwc_bf16.argtypes = [_vp] * 6 + [_i] * 11 + [_vp]
+    lib.rpg_resnet_bf16_workspace_bytes.argtypes = [_i, _i, _i, C.POINTER(_i)]
+    lib.rpg_resnet_bf16_workspace_bytes.restype = _sz
+    lib.rpg_resnet_forward_bf16.argtypes = [C.POINTER(_vp), _i, C.POINTER(_i), C.POINTER(_i), _i, _vp, _i, _i, _i, _vp,
+                                            _vp, _sz, _vp]
     lib.rpg_wino43_transform_weights_f32.argtypes = [_vp, _vp, _i, _i, _vp]
     lib.rpg_conv3x3_wino43_bn_act_nhwc_f32.argtypes = [_vp] * 6 + [_i] * 6 + [_vp]
     lib.rpg_knn_graph_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]

@@ -1,0 +1,440 @@
+// bf16 encoder path for gfx950 (BASELINE.json configs[2]: "bf16 activations + MFMA conv"): the ResNet (BasicBlock)
+// encoder with bf16 NHWC activations and bf16 weights, fp32 accumulation on v_mfma_f32_32x32x16_bf16 (16x the f32
+// matrix rate, so these convolutions are HBM/L2-bound), fp32 BatchNorm / residual / ReLU epilogue, bf16 stores.  The
+// encoder's last Linear writes fp32 features, so the GNN behind it is the unchanged fp32 path.
+//
+// The tile engine is the byte-for-byte twin of the f32 one (gemm_f32.hip) at K-step 32 elements = 64 bytes per row:
+// 16-byte staging slots, 80-byte LDS pitch (conflict-free ds_read_b128), double-buffered LDS, register staging, one
+// barrier per step, LDS-transposed epilogue.  A lane's 16-byte LDS fragment is exactly the 8 consecutive k the bf16
+// MFMA wants from it (k = 8*(lane>>5) + 0..7 of a 16-wide chunk), so no k permutation is involved here.
+// Looser parity bar than the f32 path: see tests (<= 3e-2 max-norm relative on the forward; stated there).
+#include "rpg_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int BK = 32;                 // bf16 elements per K step (64 bytes)
+constexpr int LD = BK + 8;             // LDS pitch in elements (80 bytes)
+constexpr int SLOTS = BK / 8;          // 16-byte slots per row
+constexpr int ROWS_PER_PASS = NT / SLOTS;
+
+struct EpiB {
+    const float* scale;        // fp32 per output channel (folded BN) or null
+    const float* shift;        // fp32 per output channel or null
+    const __bf16* residual;    // bf16 [M][ldc] or null
+    void* out;                 // bf16 [M][ldc], or fp32 when out_f32
+    int ldc;
+    int relu;
+    int out_f32;
+};
+
+struct ConvArgsB {
+    const __bf16* x;
+    int H, W, Cin, KH, KW, stride, pad, Ho, Wo;
+};
+
+__device__ __forceinline__ uint4 ld16_or_zero(const __bf16* p, bool ok) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (ok) v = *reinterpret_cast<const uint4*>(p);
+    return v;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NT) void conv_bf16_kernel(ConvArgsB a, const __bf16* __restrict__ Wt, int M, int N, int K,
+                                                       EpiB ep, int tiles_n) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
+    constexpr int RA = BM / ROWS_PER_PASS, RW = BN / ROWS_PER_PASS;
+    constexpr int STAGE = (BM + BN) * LD;                 // elements per LDS buffer
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int slot = tid % SLOTS, srow = tid / SLOTS;
+
+    // ---- A loader state: implicit-GEMM over NHWC bf16, k = (kh, kw, c)
+    const __bf16* img[RA];
+    int hi0[RA], wi0[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const int m = m0 + srow + ROWS_PER_PASS * j;
+        if (m < M) {
+            const int wo = m % a.Wo;
+            const int t = m / a.Wo;
+            img[j] = a.x + (size_t)(t / a.Ho) * a.H * a.W * a.Cin;
+            hi0[j] = (t % a.Ho) * a.stride - a.pad;
+            wi0[j] = wo * a.stride - a.pad;
+        } else {
+            img[j] = a.x;
+            hi0[j] = -(1 << 24);
+            wi0[j] = 0;
+        }
+    }
+    int kc, kw_, kh_;
+    {
+        const int k0 = 8 * slot;
+        kc = k0 % a.Cin;
+        const int t = k0 / a.Cin;
+        kw_ = t % a.KW;
+        kh_ = t / a.KW;
+    }
+    const __bf16* wrow[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+        const int n = n0 + srow + ROWS_PER_PASS * j;
+        wrow[j] = (n < N) ? Wt + (size_t)n * K : nullptr;
+    }
+    int kk = 8 * slot;
+
+    uint4 ra[RA], rw[RW];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int hi = hi0[j] + kh_, wi = wi0[j] + kw_;
+            const bool ok = (kh_ < a.KH) && ((unsigned)hi < (unsigned)a.H) && ((unsigned)wi < (unsigned)a.W);
+            ra[j] = ld16_or_zero(img[j] + ((hi * a.W + wi) * a.Cin + kc), ok);
+        }
+#pragma unroll
+        for (int j = 0; j < RW; ++j) rw[j] = ld16_or_zero(wrow[j] + kk, (wrow[j] != nullptr) && (kk < K));
+    };
+    auto advance = [&]() {
+        kc += BK;
+        while (kc >= a.Cin) {
+            kc -= a.Cin;
+            if (++kw_ == a.KW) { kw_ = 0; ++kh_; }
+        }
+        kk += BK;
+    };
+    auto stage = [&](int buf) {
+        __bf16* As = lds + buf * STAGE;
+        __bf16* Ws = As + BM * LD;
+#pragma unroll
+        for (int j = 0; j < RA; ++j)
+            *reinterpret_cast<uint4*>(&As[(srow + ROWS_PER_PASS * j) * LD + 8 * slot]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < RW; ++j)
+            *reinterpret_cast<uint4*>(&Ws[(srow + ROWS_PER_PASS * j) * LD + 8 * slot]) = rw[j];
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    fetch();
+    stage(0);
+    __syncthreads();
+    const int nk = (K + BK - 1) / BK;
+    const int a_off = (wm * FM * 32 + (lane & 31)) * LD + 8 * (lane >> 5);
+    const int b_off = (BM + wn * FN * 32 + (lane & 31)) * LD + 8 * (lane >> 5);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            advance();
+            fetch();
+        }
+        const __bf16* L = lds + cur * STAGE;
+#pragma unroll
+        for (int kb = 0; kb < BK; kb += 16) {
+            bf16x8 av[FM], bv[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                av[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&L[a_off + i * 32 * LD + kb]));
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                bv[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&L[b_off + j * 32 * LD + kb]));
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: transpose through a per-wave fp32 LDS slab; each lane finishes 4 consecutive channels of a row
+    constexpr int EW = FN * 32, EPITCH = EW + 4, C4 = EW / 4, RPI = 64 / C4, NIT = 32 / RPI;
+    static_assert(4 * 32 * EPITCH * 4 <= 2 * STAGE * 2, "epilogue slab does not fit the staging LDS");
+    float* slab = reinterpret_cast<float*>(lds_raw) + wave * (32 * EPITCH);
+    const int c4 = lane % C4, r_in = lane / C4;
+    const int nb = n0 + wn * EW + 4 * c4;
+    const bool n_ok = nb < N;                 // N % 4 == 0
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n_ok && ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + nb);
+    if (n_ok && ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + nb);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                slab[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * EPITCH + j * 32 + (lane & 31)] = acc[i][j][e];
+        __builtin_amdgcn_wave_barrier();
+        const int mb = m0 + (wm * FM + i) * 32;
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int row = r_in + RPI * t;
+            const int m = mb + row;
+            const float4 v = *reinterpret_cast<const float4*>(&slab[row * EPITCH + 4 * c4]);
+            if (n_ok && m < M) {
+                const size_t o = (size_t)m * ep.ldc + nb;
+                float4 y;
+                y.x = v.x * sc.x + sh.x; y.y = v.y * sc.y + sh.y; y.z = v.z * sc.z + sh.z; y.w = v.w * sc.w + sh.w;
+                if (ep.residual) {
+                    const bf16x4 rs = *reinterpret_cast<const bf16x4*>(ep.residual + o);
+                    y.x += (float)rs[0]; y.y += (float)rs[1]; y.z += (float)rs[2]; y.w += (float)rs[3];
+                }
+                if (ep.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+                if (ep.out_f32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(ep.out) + o) = y;
+                } else {
+                    const bf16x4 ob = {(__bf16)y.x, (__bf16)y.y, (__bf16)y.z, (__bf16)y.w};
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(ep.out) + o) = ob;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_tile(const ConvArgsB& a, const __bf16* w, int M, int N, int K, const EpiB& ep, hipStream_t s) {
+    constexpr int lds = 2 * (BM + BN) * LD * 2;
+    const int tn = (N + BN - 1) / BN, tm = (M + BM - 1) / BM;
+    hipLaunchKernelGGL((conv_bf16_kernel<BM, BN, WM, WN>), dim3(tm * tn), dim3(NT), lds, s, a, w, M, N, K, ep, tn);
+}
+
+// ---- streaming kernels on bf16 NHWC tensors (8 elements = 16 bytes per lane) ----
+inline int capped_grid(long items) {
+    long g = (items + NT - 1) / NT;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+// fp32 [n][3][h][w] -> bf16 [n][h][w][8] (channels 3..7 zero)
+__global__ __launch_bounds__(NT) void nchw3_to_nhwc8_bf16_kernel(const float* __restrict__ x, uint4* __restrict__ y,
+                                                                 long npix, int hw) {
+    for (long p = (long)blockIdx.x * NT + threadIdx.x; p < npix; p += (long)gridDim.x * NT) {
+        const long n = p / hw;
+        const int qd = (int)(p - n * hw);
+        const float* b = x + n * 3 * (long)hw + qd;
+        const bf16x8 v = {(__bf16)b[0], (__bf16)b[hw], (__bf16)b[2 * (long)hw], (__bf16)0.f,
+                          (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        y[p] = __builtin_bit_cast(uint4, v);
+    }
+}
+
+__global__ __launch_bounds__(NT) void maxpool3x3s2_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int h,
+                                                               int w, int c8, int ho, int wo, long total) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % c8);
+        long t = i / c8;
+        const int ox = (int)(t % wo);
+        t /= wo;
+        const int oy = (int)(t % ho);
+        const long n = t / ho;
+        const uint4* img = x + n * (long)h * w * c8;
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if ((unsigned)ix >= (unsigned)w) continue;
+                const bf16x8 v = __builtin_bit_cast(bf16x8, img[((long)iy * w + ix) * c8 + c]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], (float)v[k]);
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (__bf16)m[k];
+        y[i] = __builtin_bit_cast(uint4, o);
+    }
+}
+
+// [n][hw][c] bf16 -> [n][c] bf16 (fp32 sum, one rounding at the end)
+__global__ __launch_bounds__(NT) void global_avgpool_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int hw,
+                                                                 int c8, long total) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % c8);
+        const long n = i / c8;
+        const uint4* p = x + n * (long)hw * c8 + c;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int qd = 0; qd < hw; ++qd) {
+            const bf16x8 v = __builtin_bit_cast(bf16x8, p[(long)qd * c8]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += (float)v[k];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (__bf16)(s[k] / (float)hw);
+        y[i] = __builtin_bit_cast(uint4, o);
+    }
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
+
+}  // namespace
+
+namespace rpg {
+
+int launch_conv_bf16(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y,
+                     int n, int h, int wd, int cin, int cout, int kh, int kw, int stride, int pad, int relu, int out_f32,
+                     hipStream_t s) {
+    if (!x || !w || !y || n <= 0 || h <= 0 || wd <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 ||
+        pad < 0 || (cin & 7) || (cout & 3) || !aligned16(x) || !aligned16(w) || !aligned16(y) ||
+        (scale && !aligned16(scale)) || (shift && !aligned16(shift)) || (residual && (reinterpret_cast<uintptr_t>(residual) & 7)))
+        return RPG_ERR_BAD_ARG;
+    const int ho = conv_out(h, kh, stride, pad), wo = conv_out(wd, kw, stride, pad);
+    if (ho <= 0 || wo <= 0) return RPG_ERR_BAD_ARG;
+    const long M = (long)n * ho * wo, K = (long)kh * kw * cin;
+    if (M >= (1L << 31) || K >= (1 << 24) || (long)h * wd * cin >= (1L << 31)) return RPG_ERR_BAD_ARG;
+    ConvArgsB a{reinterpret_cast<const __bf16*>(x), h, wd, cin, kh, kw, stride, pad, ho, wo};
+    EpiB ep{scale, shift, reinterpret_cast<const __bf16*>(residual), y, cout, relu, out_f32};
+    const __bf16* wp = reinterpret_cast<const __bf16*>(w);
+    const int slot = timing_begin(RPG_TIMER_CONV, s);
+    if (cout <= 64 && M >= 65536) launch_tile<256, 64, 4, 1>(a, wp, (int)M, cout, (int)K, ep, s);
+    else if (cout <= 64 || (long)((M + 127) / 128) * ((cout + 127) / 128) < 256) launch_tile<64, 64, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);
+    else launch_tile<128, 128, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);
+    timing_end(slot, 2.0 * (double)M * cout * (double)K, s);
+    RPG_CHECK_LAUNCH("conv2d_bn_act_bf16");
+    return RPG_OK;
+}
+
+}  // namespace rpg
+
+extern "C" int rpg_conv2d_bn_act_nhwc_bf16(const void* x, const void* w_ohwi, const float* scale, const float* shift,
+                                           const void* residual, void* y, int n, int h, int w, int cin, int cout, int kh,
+                                           int kw, int stride, int pad, int relu, int out_f32, void* stream) {
+    return rpg::launch_conv_bf16(x, w_ohwi, scale, shift, residual, y, n, h, w, cin, cout, kh, kw, stride, pad, relu, out_f32,
+                                 rpg::as_stream(stream));
+}
+
+extern "C" size_t rpg_resnet_bf16_workspace_bytes(int n, int h, int w, const int* planes) {
+    if (n <= 0 || h <= 0 || w <= 0 || !planes) return 0;
+    const int h1 = conv_out(h, 7, 2, 3), w1 = conv_out(w, 7, 2, 3), h2 = conv_out(h1, 3, 2, 1), w2 = conv_out(w1, 3, 2, 1);
+    size_t blk = 0;
+    int hh = h2, ww = w2;
+    for (int l = 0; l < 4; ++l) {
+        if (l > 0) { hh = conv_out(hh, 3, 2, 1); ww = conv_out(ww, 3, 2, 1); }
+        const size_t sz = (size_t)n * hh * ww * planes[l];
+        if (sz > blk) blk = sz;
+    }
+    return align_up((size_t)n * h * w * 8 * 2, 256) + align_up((size_t)n * h1 * w1 * planes[0] * 2, 256) +
+           4 * align_up(blk * 2, 256) + align_up((size_t)n * planes[3] * 2, 256);
+}
+
+// tensors: per conv {w_ohwi bf16, scale f32, shift f32} (stem Cin padded to 8), then fc weight bf16 [feat][512], bias f32.
+extern "C" int rpg_resnet_forward_bf16(const void* const* tensors, int n_tensors, const int* blocks, const int* planes,
+                                       int feat_dim, const float* x_nchw, int n, int h, int w, float* feat, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    if (!tensors || !blocks || !planes || !x_nchw || !feat || !workspace || n <= 0 || h <= 0 || w <= 0 || feat_dim <= 0 ||
+        (feat_dim & 3))
+        return RPG_ERR_BAD_ARG;
+    int expect = 3 + 2, cin = planes[0];
+    for (int l = 0; l < 4; ++l) {
+        if (planes[l] & 7) return RPG_ERR_BAD_ARG;
+        for (int b = 0; b < blocks[l]; ++b) {
+            const int stride = (l > 0 && b == 0) ? 2 : 1;
+            expect += 6 + ((stride != 1 || cin != planes[l]) ? 3 : 0);
+            cin = planes[l];
+        }
+    }
+    if (n_tensors != expect) return RPG_ERR_BAD_ARG;
+    for (int i = 0; i < n_tensors; ++i)
+        if (!tensors[i]) return RPG_ERR_BAD_ARG;
+    if (workspace_bytes < rpg_resnet_bf16_workspace_bytes(n, h, w, planes)) return RPG_ERR_WORKSPACE;
+    hipStream_t s = rpg::as_stream(stream);
+    const int h1 = conv_out(h, 7, 2, 3), w1 = conv_out(w, 7, 2, 3), h2 = conv_out(h1, 3, 2, 1), w2 = conv_out(w1, 3, 2, 1);
+    size_t blk = 0;
+    {
+        int hh = h2, ww = w2;
+        for (int l = 0; l < 4; ++l) {
+            if (l > 0) { hh = conv_out(hh, 3, 2, 1); ww = conv_out(ww, 3, 2, 1); }
+            const size_t sz = (size_t)n * hh * ww * planes[l];
+            if (sz > blk) blk = sz;
+        }
+    }
+    char* base = reinterpret_cast<char*>(workspace);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base + off; off += align_up(bytes, 256); return reinterpret_cast<void*>(p); };
+    void* in8 = take((size_t)n * h * w * 8 * 2);
+    void* stem = take((size_t)n * h1 * w1 * planes[0] * 2);
+    void* buf[4];
+    for (int i = 0; i < 4; ++i) buf[i] = take(blk * 2);
+    void* pool = take((size_t)n * planes[3] * 2);
+
+    const long npix = (long)n * h * w;
+    hipLaunchKernelGGL(nchw3_to_nhwc8_bf16_kernel, dim3(capped_grid(npix)), dim3(NT), 0, s, x_nchw,
+                       reinterpret_cast<uint4*>(in8), npix, h * w);
+    int rc, ti = 0;
+    if ((rc = rpg::launch_conv_bf16(in8, tensors[0], (const float*)tensors[1], (const float*)tensors[2], nullptr, stem, n, h,
+                                    w, 8, planes[0], 7, 7, 2, 3, 1, 0, s)) != RPG_OK)
+        return rc;
+    ti += 3;
+    {
+        const int c8 = planes[0] / 8;
+        const long total = (long)n * h2 * w2 * c8;
+        hipLaunchKernelGGL(maxpool3x3s2_bf16_kernel, dim3(capped_grid(total)), dim3(NT), 0, s,
+                           reinterpret_cast<const uint4*>(stem), reinterpret_cast<uint4*>(buf[0]), h1, w1, c8, h2, w2, total);
+    }
+    int cur = 0, hh = h2, ww = w2;
+    cin = planes[0];
+    for (int l = 0; l < 4; ++l) {
+        for (int b = 0; b < blocks[l]; ++b) {
+            const int stride = (l > 0 && b == 0) ? 2 : 1;
+            const int c = planes[l];
+            const bool ds = (stride != 1 || cin != c);
+            const int ho = conv_out(hh, 3, stride, 1), wo = conv_out(ww, 3, stride, 1);
+            void* X = buf[cur];
+            void* T = buf[(cur + 1) & 3];
+            void* Y = buf[(cur + 2) & 3];
+            void* D = buf[(cur + 3) & 3];
+            if ((rc = rpg::launch_conv_bf16(X, tensors[ti], (const float*)tensors[ti + 1], (const float*)tensors[ti + 2],
+                                            nullptr, T, n, hh, ww, cin, c, 3, 3, stride, 1, 1, 0, s)) != RPG_OK)
+                return rc;
+            const void* identity = X;
+            if (ds) {
+                if ((rc = rpg::launch_conv_bf16(X, tensors[ti + 6], (const float*)tensors[ti + 7], (const float*)tensors[ti + 8],
+                                                nullptr, D, n, hh, ww, cin, c, 1, 1, stride, 0, 0, 0, s)) != RPG_OK)
+                    return rc;
+                identity = D;
+            }
+            if ((rc = rpg::launch_conv_bf16(T, tensors[ti + 3], (const float*)tensors[ti + 4], (const float*)tensors[ti + 5],
+                                            identity, Y, n, ho, wo, c, c, 3, 3, 1, 1, 1, 0, s)) != RPG_OK)
+                return rc;
+            ti += ds ? 9 : 6;
+            cur = (cur + 2) & 3;
+            hh = ho; ww = wo; cin = c;
+        }
+    }
+    {
+        const int c8 = cin / 8;
+        const long total = (long)n * c8;
+        hipLaunchKernelGGL(global_avgpool_bf16_kernel, dim3(capped_grid(total)), dim3(NT), 0, s,
+                           reinterpret_cast<const uint4*>(buf[cur]), reinterpret_cast<uint4*>(pool), hh * ww, c8, total);
+    }
+    // fc as a 1x1 convolution on a 1x1 image: [n][1][1][cin] x [feat][1][1][cin], bias in `shift`, fp32 output
+    return rpg::launch_conv_bf16(pool, tensors[ti], nullptr, (const float*)tensors[ti + 1], nullptr, feat, n, 1, 1, cin,
+                                 feat_dim, 1, 1, 1, 0, 0, 1, s);
+}

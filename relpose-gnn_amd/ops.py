@@ -88,6 +88,26 @@ def conv3x3_wino43_bn_act_nhwc(x: torch.Tensor, u: torch.Tensor, scale: Optional
     return y
 
 
+def conv2d_bn_act_nhwc_bf16(x: torch.Tensor, w_ohwi: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor],
+                            residual: Optional[torch.Tensor] = None, stride: int = 1, pad: int = 0, relu: bool = False,
+                            out_f32: bool = False) -> torch.Tensor:
+    """bf16 twin of conv2d_bn_act_nhwc: x / w_ohwi / residual bf16, scale / shift fp32, fp32 accumulation."""
+    x, w_ohwi = _req(x, "x", torch.bfloat16), _req(w_ohwi, "w_ohwi", torch.bfloat16)
+    n, h, w, cin = x.shape
+    cout, kh, kw, cin_w = w_ohwi.shape
+    if cin_w != cin:
+        raise ValueError(f"channel mismatch: x has {cin}, weight has {cin_w}")
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    scale = None if scale is None else _req(scale, "scale")
+    shift = None if shift is None else _req(shift, "shift")
+    residual = None if residual is None else _req(residual, "residual", torch.bfloat16)
+    L.check(L.lib().rpg_conv2d_bn_act_nhwc_bf16(_p(x), _p(w_ohwi), _p(scale), _p(shift), _p(residual), _p(y), n, h, w, cin,
+                                                 cout, kh, kw, stride, pad, int(relu), int(out_f32), _stream()),
+            "conv2d_bn_act_nhwc_bf16")
+    return y
+
+
 def maxpool3x3s2_nhwc(x: torch.Tensor) -> torch.Tensor:
     x = _req(x, "x")
     n, h, w, c = x.shape

@@ -92,6 +92,20 @@ def pack_resnet(sd: Dict[str, torch.Tensor], prefix: str = "feature_extractor.",
     return t, blocks, planes
 
 
+def pack_resnet_bf16(sd: Dict[str, torch.Tensor], prefix: str = "feature_extractor.") -> Tuple[List[torch.Tensor], List[int], List[int]]:
+    """bf16 encoder (``rpg_resnet_forward_bf16``): per conv {w_ohwi bf16 (stem Cin padded to 8), scale f32, shift f32},
+    then fc weight bf16, fc bias f32.  Weights are rounded to bf16 once (round-to-nearest-even)."""
+    t32, blocks, planes = pack_resnet(sd, prefix)
+    out: List[torch.Tensor] = []
+    for i in range(0, len(t32) - 2, 4):
+        w = t32[i]
+        if i == 0:                                       # stem: [C][7][7][4] -> [C][7][7][8]
+            w = torch.nn.functional.pad(w, (0, 8 - w.shape[-1]))
+        out += [w.to(torch.bfloat16).contiguous(), t32[i + 1], t32[i + 2]]
+    out += [t32[-2].to(torch.bfloat16).contiguous(), t32[-1]]
+    return out, blocks, planes
+
+
 GNN_TENSOR_ORDER = (
     "proj_edge", "edge_mlp.0", "edge_mlp.2", "mlp.0", "mlp.2", "att.gtp", "att.W", "mlp_updating.0", "mlp_updating.2",
     "heads.node", "heads.edge")

@@ -114,6 +114,15 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         self._gnn_ws: Dict[Tuple, torch.Tensor] = {}
         self._checked_edges: Dict[Tuple, bool] = {}
 
+    @property
+    def encoder_dtype(self) -> str:
+        """'f32' (default; the 1e-4 parity path) or 'bf16' (BASELINE configs[2]: bf16 activations + bf16 MFMA convs)."""
+        return self._enc.dtype
+
+    @encoder_dtype.setter
+    def encoder_dtype(self, dtype: str) -> None:
+        self._enc.set_dtype(dtype)
+
     # ---- packed-weight cache ------------------------------------------------------------------------------------
     def refresh_packed(self) -> None:
         """Drop the packed device copies of the weights (call after mutating parameters in place)."""

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .params import pack_resnet
+from .params import pack_resnet, pack_resnet_bf16
 
 
 class BasicBlock(nn.Module):
@@ -46,10 +46,18 @@ class EncoderRunner:
         self._packed: Optional[Tuple[List[torch.Tensor], List[int], List[int]]] = None
         self._ptrs = None
         self._ws: Dict[Tuple, torch.Tensor] = {}
+        self.dtype = "f32"          # "f32": Winograd / direct f32 MFMA kernels; "bf16": bf16 activations + bf16 MFMA
 
     def invalidate(self) -> None:
         self._packed, self._ptrs = None, None
         self._ws.clear()
+
+    def set_dtype(self, dtype: str) -> None:
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("encoder dtype must be 'f32' or 'bf16'")
+        if dtype != self.dtype:
+            self.dtype = dtype
+            self.invalidate()
 
     def run(self, state_dict_fn, prefix: str, x_nchw: torch.Tensor, slot: int = 0) -> torch.Tensor:
         if not x_nchw.is_cuda:
@@ -63,7 +71,10 @@ class EncoderRunner:
                 if any(v.device != x_nchw.device for v in sd.values() if v.is_floating_point()):
                     raise RuntimeError("encoder weights and input are on different devices")
                 from . import ops
-                self._packed = pack_resnet(sd, prefix, wino_fn=ops.wino43_transform_weights)
+                if self.dtype == "bf16":
+                    self._packed = pack_resnet_bf16(sd, prefix)
+                else:
+                    self._packed = pack_resnet(sd, prefix, wino_fn=ops.wino43_transform_weights)
             self._ptrs = L.ptr_array([None if t is None else t.data_ptr() for t in self._packed[0]])
         tensors, blocks, planes = self._packed
         x = x_nchw.contiguous()
@@ -71,16 +82,17 @@ class EncoderRunner:
         feat_dim = tensors[-2].shape[0]
         planes_c = L.int_array(planes)
         key = (n, h, w, x.device)
+        bf16 = self.dtype == "bf16"
         ent = self._ws.get(slot)          # one workspace per concurrent stream slot, kept for the last shape seen
         if ent is None or ent[0] != key:
-            nbytes = lib.rpg_resnet_workspace_bytes(n, h, w, planes_c)
+            nbytes = (lib.rpg_resnet_bf16_workspace_bytes if bf16 else lib.rpg_resnet_workspace_bytes)(n, h, w, planes_c)
             ent = (key, torch.empty(nbytes, dtype=torch.uint8, device=x.device))
             self._ws[slot] = ent
         ws = ent[1]
         feat = torch.empty((n, feat_dim), dtype=torch.float32, device=x.device)
-        rc = lib.rpg_resnet_forward_f32(self._ptrs, len(tensors), L.int_array(blocks), planes_c, feat_dim, x.data_ptr(),
-                                        n, h, w, feat.data_ptr(), ws.data_ptr(), ws.numel(),
-                                        torch.cuda.current_stream().cuda_stream)
+        fwd = lib.rpg_resnet_forward_bf16 if bf16 else lib.rpg_resnet_forward_f32
+        rc = fwd(self._ptrs, len(tensors), L.int_array(blocks), planes_c, feat_dim, x.data_ptr(), n, h, w, feat.data_ptr(),
+                 ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
         L.check(rc, "resnet_forward")
         return feat
 
