@@ -316,3 +316,35 @@ def test_conv3x3_winograd(dev, n, h, w, cin, cout, res, relu):
                                        None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev), relu=relu)
     err = rel_err(y.cpu().permute(0, 3, 1, 2), ref)
     assert err < 2e-5, err
+
+
+def test_composite_abi_error_codes(dev):
+    """rpg_resnet_forward_f32 / rpg_gnn_forward_f32 reject a wrong tensor table or a short workspace with status codes
+    (no launch, no exception across the ABI)."""
+    from relpose_gnn_amd import _lib
+    lib = _lib.lib()
+    planes, blocks = _lib.int_array([8, 16, 32, 64]), _lib.int_array([1, 1, 1, 1])
+    x = torch.zeros(2, 3, 32, 32, device=dev)
+    feat = torch.zeros(2, 64, device=dev)
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+    junk = torch.zeros(16, device=dev)
+    ptrs = _lib.ptr_array([junk.data_ptr()] * 5)
+    rc = lib.rpg_resnet_forward_f32(ptrs, 5, blocks, planes, 64, x.data_ptr(), 2, 32, 32, feat.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), None)
+    assert rc == _lib.RPG_ERR_BAD_ARG                                   # wrong number of tensors
+    n_t = 4 + 8 * 4 + 4 * 3 + 2
+    ptrs = _lib.ptr_array([junk.data_ptr()] * n_t)
+    rc = lib.rpg_resnet_forward_f32(ptrs, n_t, blocks, planes, 64, x.data_ptr(), 2, 32, 32, feat.data_ptr(), ws.data_ptr(), 16, None)
+    assert rc == _lib.RPG_ERR_WORKSPACE
+    ei = torch.zeros(2, 4, dtype=torch.int64, device=dev)
+    out = torch.zeros(64, device=dev)
+    st = torch.zeros(1, dtype=torch.int32, device=dev)
+    g = _lib.ptr_array([junk.data_ptr()] * 22)
+    rc = lib.rpg_gnn_forward_f32(g, 22, feat.data_ptr(), ei.data_ptr(), ei.data_ptr() + 32, 0, 2, 4, 64, 2, out.data_ptr(),
+                                 out.data_ptr(), None, None, st.data_ptr(), ws.data_ptr(), 16, None)
+    assert rc == _lib.RPG_ERR_WORKSPACE
+    rc = lib.rpg_gnn_forward_f32(g, 21, feat.data_ptr(), ei.data_ptr(), ei.data_ptr() + 32, 0, 2, 4, 64, 2, out.data_ptr(),
+                                 out.data_ptr(), None, None, st.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert rc == _lib.RPG_ERR_BAD_ARG
+    with pytest.raises(_lib.RpgError):
+        _lib.check(_lib.RPG_ERR_WORKSPACE, "x")
