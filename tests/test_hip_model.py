@@ -287,3 +287,22 @@ def test_gnn_node_split_equals_reference_formulation(dev, golden_dir):
     ea, er = rel_err(outs[1][0], outs[0][0]), rel_err(outs[1][1], outs[0][1])
     _report("gnn_node_split_vs_reference_formulation_R3_64px", ea, er)
     assert ea < TOL and er < TOL
+
+
+def test_graph_replay_equals_eager(dev):
+    """The forward captured into a HIP graph (both worker streams joined by events) replays to the same poses, also
+    after the static input has been overwritten with a new batch."""
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd.graphed import GraphedForward
+    m, _ = _build(64, 32, (8, 16, 32, 64), (1, 1, 1, 1), dev)
+    d1 = _data(S.synth_images(8 * 6, 32, 40, seed=31), 8, dev)
+    d2 = _data(S.synth_images(8 * 6, 32, 40, seed=32), 8, dev)
+    e1 = tuple(t.clone() for t in m(d1)[:2])
+    e2 = tuple(t.clone() for t in m(d2)[:2])
+    runner = GraphedForward(m, _data(S.synth_images(8 * 6, 32, 40, seed=31), 8, dev))
+    a, r, ei = runner(d1)
+    assert torch.equal(a, e1[0]) and torch.equal(r, e1[1]) and ei.shape == (2, 56 * 6)
+    a, r, _ = runner(d2)
+    assert torch.equal(a, e2[0]) and torch.equal(r, e2[1])
+    with pytest.raises(ValueError):
+        runner(_data(S.synth_images(8 * 4, 32, 40, seed=33), 8, dev))

@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--tile", type=int, default=-1)
     ap.add_argument("--sk", type=int, default=1)
     ap.add_argument("--wino", type=int, default=1)
+    ap.add_argument("--nimg", type=int, default=256, help="images in the batch (256 = 32 graphs)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ops.set_tuning(ops.TUNE_BK, args.bk)
@@ -68,6 +69,7 @@ def main():
     for name, n, h, w, cin, cout, k, s, p, res in SHAPES:
         if args.only and args.only not in name:
             continue
+        n = args.nimg
         x = torch.randn(n, h, w, cin, device=dev)
         wt = torch.randn(cout, k, k, cin, device=dev) * (2.0 / (cin * k * k)) ** 0.5
         sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.1
