@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[3]/[4]: an evaluation-shaped STREAM of query graphs through the HIP module, sharded over the
+ranks of one node and collated with one all-gather (RCCL) of the derived query poses.
+
+    python tools/eval_stream.py --graphs 2000 --shape 256x341                      # 7-Scenes 'chess' test split size
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29500 \\
+        tools/eval_stream.py --graphs 2000 --shape 256x341
+    ... --graphs 17000 --encoder-dtype bf16                                        # configs[4]: all seven scenes, bf16 encoder
+
+Pixels are synthetic (no dataset here); the edge lists are the reference's fully-connected 8-node graphs; every graph
+goes through the same post-processing as testing/test.py:213-251 (`relpose_gnn_amd.evaluate`).  The reference evaluates
+with batch_size=1; graphs are independent, so they are micro-batched here (--micro-batch).  Prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--graphs", type=int, default=2000)
+    ap.add_argument("--shape", default="256x341")
+    ap.add_argument("--micro-batch", type=int, default=32)
+    ap.add_argument("--encoder-dtype", choices=("f32", "bf16"), default="f32")
+    args = ap.parse_args()
+    h, w = (int(v) for v in args.shape.split("x"))
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd import evaluate as E
+    from relpose_gnn_amd.graph import fc_batch
+    from relpose_gnn_amd.posenet import PoseNetX_R2
+    from relpose_gnn_amd.resnet import resnet34
+    from relpose_gnn_amd.shard import gather_rows, shard_counts, shard_range
+
+    D = 2048
+    model = PoseNetX_R2(resnet34(), droprate=0.0, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D,
+                        input_img_height=h, use_gnn=True, knn=-1, use_AP=True, gnn_recursion=2)
+    model.load_state_dict(S.synth_state_dict(S.posenet_r2_param_shapes(D, D, D), seed=1))
+    model = model.to(dev).eval()
+    model.encoder_dtype = args.encoder_dtype
+
+    lo, hi = shard_range(args.graphs, rank, world)
+    mb = args.micro_batch
+    gen = torch.Generator(device=dev).manual_seed(77 + rank)
+    x = torch.randn((8 * mb, 3 * h * w), generator=gen, device=dev)           # pixel buffer reused by every micro-batch
+    y = torch.randn((8 * mb, 6), generator=gen, device=dev) * 0.3              # ground-truth poses (t, log q)
+    pm, ps = np.zeros(3), np.ones(3)
+
+    def run(count):
+        preds = []
+        done = 0
+        while done < count:
+            g = min(mb, count - done)
+            batch = fc_batch(x[: 8 * g], 8, y[: 8 * g])
+            _, rel, ei = model(batch)
+            rel_c, y_c, ei_c = rel.cpu().numpy(), batch.y.cpu().numpy(), ei.cpu().numpy()      # D2H as test.py:214 does
+            for k in range(g):
+                p, _ = E.query_pose(rel_c[56 * k: 56 * (k + 1)], y_c[8 * k: 8 * (k + 1)], ei_c[:, 56 * k: 56 * (k + 1)] - 8 * k, pm, ps)
+                preds.append(p)
+            done += g
+        return np.stack(preds) if preds else np.zeros((0, 7))
+
+    run(min(mb, hi - lo))                                                      # warm-up (packing, workspaces)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    local_pred = run(hi - lo)
+    poses = gather_rows(torch.from_numpy(local_pred).to(dev), shard_counts(args.graphs, world)) if world > 1 else local_pred
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        assert len(poses) == args.graphs
+        print(json.dumps({"workload": f"eval-shape stream: {args.graphs} 8-node FC graphs, {h}x{w}, encoder {args.encoder_dtype}, "
+                                      f"micro-batch {mb}, D2H + test.py post-processing per graph included",
+                          "n_gpus": world, "graphs": args.graphs, "seconds": round(dt, 3),
+                          "graphs_per_s": round(args.graphs / dt, 1)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
