@@ -197,6 +197,10 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         if not x.is_cuda:
             raise RuntimeError("PoseNetX_R2 (HIP) needs its inputs on the GPU: call data.to(device) first "
                                "(there is no CPU fallback)")
+        if not torch.is_tensor(edge_index) or edge_index.device != x.device:
+            raise RuntimeError("data.edge_index must be a tensor on the same GPU as data.x")
+        if x.dtype != torch.float32:
+            raise TypeError(f"data.x must be float32 (the reference's input dtype), got {x.dtype}")
         lib = _L.lib()
         x = x.view(x.size(0), 3, self.input_img_height, -1)                       # posenet.py:1035
         self._pack_gnn()

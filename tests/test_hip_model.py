@@ -136,6 +136,14 @@ def test_module_contract(dev):
     assert a.device.type == "cuda" and int((ei.cpu()[1] == 0).nonzero()[0]) == 28      # reference edge (1 -> 0)
     with pytest.raises(RuntimeError):
         m(_data(x, 8, torch.device("cpu")))                 # no CPU fallback
+    mixed = _data(x, 8, dev)
+    mixed.edge_index = mixed.edge_index.cpu()
+    with pytest.raises(RuntimeError):
+        m(mixed)                                            # edge_index left on the host
+    half = _data(x, 8, dev)
+    half.x = half.x.half()
+    with pytest.raises(TypeError):
+        m(half)
     bad = _data(x, 8, dev)
     bad.edge_index = bad.edge_index.clone()
     bad.edge_index[0, 5] = 99
