@@ -50,7 +50,7 @@ def parse():
     return ap.parse_args()
 
 
-CPU_THREADS_PER_WORKER = 32      # measured optimum of torch-CPU for this model on the EPYC host (tools/cpu_threads_probe.py)
+CPU_THREADS_PER_WORKER = 32      # measured optimum of torch-CPU for this model on the EPYC host (tests/probes/cpu_threads_probe.py)
 
 
 def cpu_worker(budget_s: float, threads: int):
@@ -76,7 +76,7 @@ def cpu_worker(budget_s: float, threads: int):
 
 def cpu_baseline(budget_s: float):
     """The CPU oracle at the configuration that is FASTEST on the GPU box's host (2x EPYC 9575F, 128 cores), measured
-    with tools/cpu_threads_probe.py and this function: one process x 32 torch threads = 12.1 graphs/s; 16 threads 10.7;
+    with tests/probes/cpu_threads_probe.py and this function: one process x 32 torch threads = 12.1 graphs/s; 16 threads 10.7;
     64 threads 7.1; 128 threads 3.3; 256 threads 0.1; four concurrent 32-thread processes 8.0 in total (memory-bound
     oneDNN convolutions do not scale across the sockets).  Started as a child process BEFORE this process touches the
     GPU; `cores` reports the threads actually used."""

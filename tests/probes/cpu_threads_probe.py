@@ -6,7 +6,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import relpose_gnn_amd.synth as S  # noqa: E402
 from oracle import posenet_ref as O  # noqa: E402
 
