@@ -83,28 +83,54 @@ def errors(pred_poses: np.ndarray, targ_poses: np.ndarray) -> EvalResult:
 def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 32, pose_m=(0.0, 0.0, 0.0),
                     pose_s=(1.0, 1.0, 1.0), ref_node: int = 0, rank: int = 0, world: int = 1) -> EvalResult:
     """Run ``model`` over a stream of single-graph ``Data`` objects (x, edge_index, y) and post-process like test.py.
-    With world > 1 every rank evaluates its contiguous block (shard_range) and the [G,7] rows are all-gathered."""
+    With world > 1 every rank evaluates its contiguous block (shard_range) and the [G,7] rows are all-gathered.
+
+    The loop is software-pipelined: the forward of micro-batch i+1 is enqueued (and its relative poses copied to pinned
+    host memory asynchronously) before the host post-processes micro-batch i, so the numpy work of test.py:213-251
+    overlaps the GPU instead of idling it."""
     from .shard import gather_rows, shard_counts, shard_range
     pose_m, pose_s = np.asarray(pose_m, dtype=np.float64), np.asarray(pose_s, dtype=np.float64)
     lo, hi = shard_range(len(graphs), rank, world)
+    on_gpu = torch.device(device).type == "cuda"
     preds: List[np.ndarray] = []
     targs: List[np.ndarray] = []
-    for b0 in range(lo, hi, micro_batch):
+
+    def launch(b0):
         chunk = [graphs[i] for i in range(b0, min(hi, b0 + micro_batch))]
-        batch = Batch.from_data_list(chunk).to(device)
+        batch = Batch.from_data_list(chunk).to(device, non_blocking=True)
         _, rel, edge_index = model(batch)
-        rel = rel.cpu().numpy()
-        edges = edge_index.cpu().numpy()
-        e0 = n0 = 0
+        if edge_index.shape[1] != sum(c.edge_index.shape[1] for c in chunk):          # kNN graph returned by the model
+            raise NotImplementedError("per-graph slicing of model-built (kNN) edge lists")
+        if on_gpu:
+            host = torch.empty(rel.shape, dtype=rel.dtype, pin_memory=True)
+            host.copy_(rel, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = rel, None
+        return chunk, host, ev
+
+    def finish(item):
+        chunk, host, ev = item
+        if ev is not None:
+            ev.synchronize()
+        rel = host.numpy()
+        e0 = 0
         for g in chunk:
-            n, e = g.num_nodes, g.edge_index.shape[1]
-            if edges.shape[1] != sum(c.edge_index.shape[1] for c in chunk):      # kNN graph returned by the model
-                raise NotImplementedError("per-graph slicing of model-built (kNN) edge lists")
-            p, t = query_pose(rel[e0:e0 + e], g.y.cpu().numpy(), edges[:, e0:e0 + e] - n0, pose_m, pose_s, ref_node)
+            e = g.edge_index.shape[1]
+            p, t = query_pose(rel[e0:e0 + e], g.y.cpu().numpy(), g.edge_index.cpu().numpy(), pose_m, pose_s, ref_node)
             preds.append(p)
             targs.append(t)
             e0 += e
-            n0 += n
+
+    pending = None
+    for b0 in range(lo, hi, micro_batch):
+        item = launch(b0)
+        if pending is not None:
+            finish(pending)
+        pending = item
+    if pending is not None:
+        finish(pending)
     pred = np.stack(preds) if preds else np.zeros((0, 7))
     targ = np.stack(targs) if targs else np.zeros((0, 7))
     if world > 1:
