@@ -1,0 +1,135 @@
+"""Seeded random-shape sweeps of the tile engine front-ends against PyTorch-CPU fp32: odd kernel sizes, strides, paddings,
+channel counts that are not tile multiples, ragged M / N / K, every residual / ReLU / scale combination.  Complements the
+hand-picked shapes of test_hip_ops.py (which cover the ResNet34 / GNN layer shapes)."""
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_conv_direct(dev, case):
+    from relpose_gnn_amd import ops
+    rng = random.Random(1000 + case)
+    kh, kw = rng.choice([1, 2, 3, 5, 7]), rng.choice([1, 2, 3, 5])
+    stride, pad = rng.choice([1, 2, 3]), rng.choice([0, 1, 2, 3])
+    cin, cout = 4 * rng.randint(1, 24), rng.choice([4, 12, 32, 60, 64, 100, 128, 200])
+    n, h, w = rng.randint(1, 5), rng.randint(max(kh - 2 * pad, 1), 30), rng.randint(max(kw - 2 * pad, 1), 30)
+    if (h + 2 * pad - kh) < 0 or (w + 2 * pad - kw) < 0:
+        pytest.skip("empty output")
+    res, relu, has_scale = rng.random() < 0.5, rng.random() < 0.5, rng.random() < 0.7
+    x = _rand(n, cin, h, w, seed=case)
+    wt = _rand(cout, cin, kh, kw, seed=case + 1, scale=(1.0 / (cin * kh * kw)) ** 0.5)
+    scale = (torch.rand(cout, generator=torch.Generator().manual_seed(case + 2)) + 0.5) if has_scale else None
+    shift = _rand(cout, seed=case + 3, scale=0.2)
+    ref = F.conv2d(x, wt, None, stride=stride, padding=pad)
+    if scale is not None:
+        ref = ref * scale.view(1, -1, 1, 1)
+    ref = ref + shift.view(1, -1, 1, 1)
+    r = None
+    if res:
+        r = _rand(*ref.shape, seed=case + 4)
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    y = ops.conv2d_bn_act_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev),
+                               None if scale is None else scale.to(dev), shift.to(dev),
+                               None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev), stride=stride, pad=pad, relu=relu)
+    assert rel_err(y.cpu().permute(0, 3, 1, 2), ref) < 1e-5, (kh, kw, stride, pad, cin, cout, n, h, w)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_random_conv_winograd(dev, case):
+    from relpose_gnn_amd import ops
+    rng = random.Random(2000 + case)
+    cin, cout = 4 * rng.randint(1, 40), 4 * rng.randint(1, 50)
+    n, h, w = rng.randint(1, 6), rng.randint(1, 20), rng.randint(1, 37)
+    res, relu = rng.random() < 0.5, rng.random() < 0.5
+    x = _rand(n, cin, h, w, seed=case)
+    wt = _rand(cout, cin, 3, 3, seed=case + 1, scale=(1.0 / (cin * 9)) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(case + 2)) + 0.5
+    shift = _rand(cout, seed=case + 3, scale=0.2)
+    ref = F.conv2d(x, wt, None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    r = None
+    if res:
+        r = _rand(*ref.shape, seed=case + 4)
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    u = ops.wino43_transform_weights(wt.permute(0, 2, 3, 1).contiguous().to(dev))
+    y = ops.conv3x3_wino43_bn_act_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), u, scale.to(dev), shift.to(dev),
+                                       None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev), relu=relu)
+    assert rel_err(y.cpu().permute(0, 3, 1, 2), ref) < 2e-5, (cin, cout, n, h, w)
+
+
+@pytest.mark.parametrize("case", range(20))
+def test_random_linear_gather(dev, case):
+    from relpose_gnn_amd import ops
+    rng = random.Random(3000 + case)
+    ns = rng.randint(1, 3)
+    widths = [4 * rng.randint(1, 90) for _ in range(ns)]
+    m, n_out, rows = rng.randint(1, 700), rng.randint(1, 300), rng.randint(1, 60)
+    g0 = torch.Generator().manual_seed(case)
+    srcs, cat = [], []
+    for i, wd in enumerate(widths):
+        if rng.random() < 0.6:
+            a = _rand(rows, wd, seed=case * 7 + i)
+            idx = torch.randint(0, rows, (m,), generator=g0)
+            srcs.append((a.to(dev), idx.to(dev)))
+            cat.append(a[idx])
+        else:
+            a = _rand(m, wd, seed=case * 7 + i)
+            srcs.append((a.to(dev), None))
+            cat.append(a)
+    k = sum(widths)
+    wl, bias = _rand(n_out, k, seed=case + 50, scale=k ** -0.5), _rand(n_out, seed=case + 51)
+    res = _rand(m, n_out, seed=case + 52) if rng.random() < 0.5 else None
+    relu = rng.random() < 0.5
+    ref = F.linear(torch.cat(cat, 1), wl, bias)
+    if res is not None:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    y = ops.linear_gather(srcs, wl.to(dev), bias.to(dev), m, None if res is None else res.to(dev), relu)
+    assert rel_err(y.cpu(), ref) < 1e-5, (widths, m, n_out)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_conv_bf16(dev, case):
+    from relpose_gnn_amd import ops
+    rng = random.Random(4000 + case)
+    kh = kw = rng.choice([1, 3, 5])
+    stride, pad = rng.choice([1, 2]), rng.choice([0, 1, 2])
+    cin, cout = 8 * rng.randint(1, 20), 4 * rng.randint(1, 40)
+    n, h, w = rng.randint(1, 4), rng.randint(kh, 24), rng.randint(kw, 24)
+    res, relu = rng.random() < 0.5, rng.random() < 0.5
+    x = _rand(n, cin, h, w, seed=case).bfloat16()
+    wt = _rand(cout, cin, kh, kw, seed=case + 1, scale=(1.0 / (cin * kh * kw)) ** 0.5).bfloat16()
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(case + 2)) + 0.5
+    shift = _rand(cout, seed=case + 3, scale=0.2)
+    ref = F.conv2d(x.float(), wt.float(), None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    r = None
+    if res:
+        r = _rand(*ref.shape, seed=case + 4).bfloat16()
+        ref = ref + r.float()
+    if relu:
+        ref = F.relu(ref)
+    y = ops.conv2d_bn_act_nhwc_bf16(x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev),
+                                    scale.to(dev), shift.to(dev), None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev),
+                                    stride=stride, pad=pad, relu=relu)
+    assert rel_err(y.float().cpu().permute(0, 3, 1, 2), ref) < 1e-2, (kh, stride, pad, cin, cout, n, h, w)
