@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU the batch is spread over in the timed region")
+    ap.add_argument("--bf16-bk", type=int, default=0, help="K step of the bf16 conv kernel (32|64; 0 = library default)")
     ap.add_argument("--encoder-dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 = the headline configuration (configs[1]); bf16 = configs[2] (bf16 activations + MFMA conv)")
     return ap.parse_args()
@@ -136,6 +137,8 @@ def main():
     model = model.to(dev).eval()
     model.hip_streams = args.streams
     model.encoder_dtype = args.encoder_dtype
+    if args.bf16_bk:
+        ops.set_tuning(ops.TUNE_BF16_BK, args.bf16_bk)
 
     B = args.graphs
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -182,6 +185,8 @@ def main():
         kt = ops.timing_read()
         model.hip_streams = args.streams
     model.encoder_dtype = args.encoder_dtype
+    if args.bf16_bk:
+        ops.set_tuning(ops.TUNE_BF16_BK, args.bf16_bk)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -57,5 +57,6 @@ int launch_linear(const GatherSrc& src, const float* weight, const float* bias, 
 int launch_gather_add2_relu(const float* pq, const int64_t* lo, const int64_t* hi, const float* bias, float* out, int e,
                             int d, hipStream_t s);
 bool gnn_split_enabled();
+void bf16_set_bk(int bk);
 
 }  // namespace rpg
