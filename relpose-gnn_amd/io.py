@@ -41,11 +41,21 @@ class _Shell:
             self.__dict__["_state"] = state
 
 
+_SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray",
+                  "complex", "slice", "range", "object"}
+
+
 class _Unpickler(pickle.Unpickler):
+    """PyG classes -> neutral shells; otherwise only tensor-rebuilding helpers of torch / numpy / collections and plain
+    builtin containers are resolved (a sample file is data: nothing else has any business being unpickled from it)."""
+
     def find_class(self, module: str, name: str):
         if module == "torch_geometric" or module.startswith("torch_geometric."):
             return type(name, (_Shell,), {"__module__": module})
-        return super().find_class(module, name)
+        root = module.split(".")[0]
+        if root in ("torch", "numpy", "collections") or (module == "builtins" and name in _SAFE_BUILTINS):
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"refusing to unpickle {module}.{name} from a graph sample file")
 
 
 class _PickleModule:

@@ -110,6 +110,11 @@ def test_graph_reader_without_pyg(tmp_path, layout):
     torch.save({"z": 1}, bad)
     with pytest.raises(ValueError):
         rio.load_graph(str(bad))
+    evil = tmp_path / "evil.pt"
+    torch.save({"x": x, "edge_index": ei, "f": os.system}, evil)       # a callable from an arbitrary module
+    with pytest.raises(Exception) as exc:
+        rio.load_graph(str(evil))
+    assert "refusing to unpickle" in str(exc.value)
 
 
 def test_checkpoint_reader(tmp_path):
