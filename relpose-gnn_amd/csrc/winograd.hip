@@ -13,7 +13,7 @@
 // in registers at the end (the output transform is lane-local: the MFMA C layout puts the same (tile, cout) element
 // of all 6 products in the same lane).  Workgroup = 4 waves on 64 tiles (= 256 output pixels) x 64 output channels;
 // a wave owns 32 tiles x 32 channels x 6 positions = 6 accumulators of 32x32.  K advances 16 at a time through ONE
-// LDS buffer pair (A: V[6][64][16+4], B: U[6][64][16+4] = 60 KB, two workgroups per CU): the raw pixels / weights of
+// LDS buffer pair (A: V[6][64][16], B: U[6][64][16] = 48 KB, chunk-swizzled; two workgroups per CU by VGPRs): the raw pixels / weights of
 // step t+1 are fetched into registers while the 48 MFMAs of step t run, the input transform is applied when they
 // are written to LDS between two barriers.  Epilogue: output transform, then the same LDS-transposed 16-byte
 // BatchNorm / residual / ReLU / store as the direct kernel, two of the four pixel columns at a time.
@@ -27,11 +27,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int NT = 256;
-constexpr int BK = 16, LD = BK + 4;      // K step and LDS pitch (floats)
+constexpr int BK = 16, LD = BK;          // K step = LDS pitch (floats): no padding, 16-byte chunks XOR-swizzled by row
 constexpr int P = 6;                     // Winograd positions
 constexpr int BMT = 64, BN = 64;         // tiles x output channels per workgroup
 constexpr int A_FLOATS = P * BMT * LD, B_FLOATS = P * BN * LD;
-constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS) * (int)sizeof(float);     // 61,440
+constexpr int LDS_BYTES = (A_FLOATS + B_FLOATS) * (int)sizeof(float);     // 49,152
 
 struct Epi {
     const float* scale;
@@ -71,62 +71,64 @@ __global__ __launch_bounds__(NT, 2) void wino43_conv_kernel(const float* __restr
     const int wm = wave >> 1, wn = wave & 1;
     const int row = tid >> 2, slot = tid & 3;          // this thread stages tile-row `row`, k-slot `slot`
 
-    // ---- A side: the 6 input pixels of tile m0+row, channels [c, c+4) of kernel row kh.
-    // All global reads are raw buffer loads: an out-of-range lane gets offset 0x80000000 >= num_records and the
-    // hardware returns zeros, so image borders, the K tail and ragged tiles cost neither a branch nor a select and
-    // the 12 loads of a step are one straight-line block.  The A descriptor is based at the first image this
-    // workgroup touches (wave-uniform), so 32-bit byte offsets suffice for any batch size.
+    // ---- staging addresses.  All global reads are raw buffer loads: an invalid lane carries the offset 0x80000000
+    // >= num_records and the hardware returns zeros, so image borders and ragged tiles cost neither a branch nor a
+    // select on the data.  Everything that depends on the lane is K-invariant and lives in 7 VGPRs (va[6], vb); what
+    // changes with the K step is wave-uniform and goes into the instruction's scalar offset:
+    //   A: pixel (ho-1+kh, wi0+j), channels c0+4*slot..   = base' + va[j] + 4*(kh*W*Cin + c0)   (base' = image - one row)
+    //   B: U[xi][n0+row][kh][c0+4*slot..]                  = U + vb + 4*(xi*Cout*K + kh*Cin + c0)
+    // Only the validity of the image row (top / bottom border) depends on both lane and kh: one bit test + 6 selects.
     const int n_first = (m0 / Tw) / H;
     const size_t img_floats = (size_t)H * W * Cin;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + n_first * img_floats), 0,
-                                                                         0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x + n_first * img_floats) - (size_t)W * Cin, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, 0x7fffffff, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const int m = m0 + row;
-    int img_off = 0, hi0 = -(1 << 24), wi0 = 0;
-    if (m < M) {
-        const int tw = m % Tw;
-        const int t = m / Tw;
-        const int ho = t % H;
-        const int n = t / H;
-        img_off = (n - n_first) * (int)img_floats;
-        hi0 = ho - 1;
-        wi0 = 4 * tw - 1;
-    }
-    int c = 4 * slot, kh = 0;
-    while (c >= Cin) { c -= Cin; ++kh; }
-    // ---- B side: U[xi][n0+row][k]
-    const int nrow = n0 + row;
-    const bool nrow_ok = nrow < Cout;
-    const unsigned ustride_b = (unsigned)Cout * K * 4u;
-    int kk = 4 * slot;
-
-    float4 d[P], ub[P];
-    auto fetch = [&]() {
-        // validity as 0 / ~0 masks combined with bit operations: no short-circuit control flow for the compiler to
-        // thread branches through
-        const int hi = hi0 + kh;
-        const unsigned rmask = 0u - ((unsigned)(kh < 3) & (unsigned)((unsigned)hi < (unsigned)H));
-        const int row_off = img_off + hi * W * Cin + c;
+    unsigned va[P];
+    unsigned rowbits = 0;                 // bit kh set <=> image row ho-1+kh exists (and the tile itself does)
+    {
+        int img_off = 0, ho = 0, wi0 = -(1 << 24);
+        if (m < M) {
+            const int tw = m % Tw;
+            const int t = m / Tw;
+            ho = t % H;
+            img_off = (t / H - n_first) * (int)img_floats;
+            wi0 = 4 * tw - 1;
+            rowbits = (ho > 0 ? 1u : 0u) | 2u | (ho < H - 1 ? 4u : 0u);
+        }
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const int wi = wi0 + j;
-            const unsigned mask = rmask & (0u - (unsigned)((unsigned)wi < (unsigned)W));
-            const unsigned off = ((4u * (unsigned)(row_off + wi * Cin)) & mask) | (OOB & ~mask);
-            d[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, off, 0, 0));
+            va[j] = (unsigned)wi < (unsigned)W ? 4u * (unsigned)(img_off + (ho * W + wi) * Cin + 4 * slot) : OOB;
         }
-        const unsigned umask = 0u - ((unsigned)nrow_ok & (unsigned)(kk < K));
-        const unsigned uoff = 4u * (unsigned)(nrow * K + kk);
-#pragma unroll
-        for (int xi = 0; xi < P; ++xi) {
-            const unsigned off = ((uoff + xi * ustride_b) & umask) | (OOB & ~umask);
-            ub[xi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 0));
+    }
+    const int nrow = n0 + row;
+    const unsigned vb = nrow < Cout ? 4u * (unsigned)(nrow * K + 4 * slot) : OOB;
+    const unsigned ustride_b = (unsigned)Cout * K * 4u;
+    const int nk = 3 * ((Cin + BK - 1) / BK);      // K steps: each kernel row is walked in steps of 16 channels
+    int f_kt = 0, f_kh = 0, f_c0 = 0;     // the K step the next fetch() loads (wave-uniform)
+
+    float4 d[P], ub[P];
+    // fetch_one(i), i = 0..11: load i of the 12 of K step f_kt (A pixels 0..5, then U positions 0..5); fetch_next()
+    // moves on to the following step.  Split like this so that the main loop can drop the loads one at a time between
+    // MFMAs.
+    auto fetch_one = [&](int i) {
+        const bool cv = f_c0 + 4 * slot < Cin;            // channel tail of a kernel row when Cin % 16 != 0
+        if (i < P) {
+            const bool rv = ((rowbits >> f_kh) & 1u) && cv;
+            const unsigned sa = 4u * (unsigned)(f_kh * W * Cin + f_c0);
+            d[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, rv ? va[i] : OOB, sa, 0));
+        } else {
+            const unsigned vbe = (f_kt < nk && cv) ? vb : OOB;
+            const unsigned sb = 4u * (unsigned)(f_kh * Cin + f_c0) + (unsigned)(i - P) * ustride_b;
+            ub[i - P] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, vbe, sb, 0));
         }
     };
-    auto advance = [&]() {
-        c += BK;
-        while (c >= Cin) { c -= Cin; ++kh; }
-        kk += BK;
+    auto fetch_next = [&]() {
+        ++f_kt;
+        f_c0 += BK;
+        if (f_c0 >= Cin) { f_c0 = 0; ++f_kh; }
     };
     auto stage = [&]() {
         // input transform V = BT d  (BT of F(4,3), interpolation points 0, +-1, +-2, inf)
@@ -141,14 +143,18 @@ __global__ __launch_bounds__(NT, 2) void wino43_conv_kernel(const float* __restr
         const float4 v3 = add(s34, q34);
         const float4 v4 = sub(s34, q34);
         const float4 v5 = add(lin(4.f, d[1], -5.f, d[3]), d[5]);
-        float* ap = As + row * LD + 4 * slot;
+        // chunk (row, slot) lives at slot ^ ((row >> 2) & 3): with a 64-byte pitch this makes both the 8-lane groups
+        // of these ds_write_b128 (2 rows x 4 chunks = 32 distinct banks) and the 16-lane groups of the ds_read_b128
+        // below (rows {0-3,12-15,20-27} / {4-11,16-19,28-31} of one logical chunk) conflict-free
+        const int sw = 4 * (slot ^ ((row >> 2) & 3));
+        float* ap = As + row * LD + sw;
         *reinterpret_cast<float4*>(ap + 0 * BMT * LD) = v0;
         *reinterpret_cast<float4*>(ap + 1 * BMT * LD) = v1;
         *reinterpret_cast<float4*>(ap + 2 * BMT * LD) = v2;
         *reinterpret_cast<float4*>(ap + 3 * BMT * LD) = v3;
         *reinterpret_cast<float4*>(ap + 4 * BMT * LD) = v4;
         *reinterpret_cast<float4*>(ap + 5 * BMT * LD) = v5;
-        float* bp = Bs + row * LD + 4 * slot;
+        float* bp = Bs + row * LD + sw;
 #pragma unroll
         for (int xi = 0; xi < P; ++xi) *reinterpret_cast<float4*>(bp + xi * BN * LD) = ub[xi];
     };
@@ -159,30 +165,44 @@ __global__ __launch_bounds__(NT, 2) void wino43_conv_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[xi][e] = 0.f;
 
-    const int a_off = (wm * 32 + (lane & 31)) * LD + 4 * (lane >> 5);
-    const int b_off = (wn * 32 + (lane & 31)) * LD + 4 * (lane >> 5);
-    const int nk = (K + BK - 1) / BK;
-    fetch();
+    const int rsw = 4 * ((lane >> 5) ^ ((lane >> 2) & 3));            // logical chunk (lane>>5) [+2 for kb = 8: ^ 8 floats]
+    const int a_off = (wm * 32 + (lane & 31)) * LD + rsw;
+    const int b_off = (wn * 32 + (lane & 31)) * LD + rsw;
+#pragma unroll
+    for (int i = 0; i < 2 * P; ++i) fetch_one(i);
+    fetch_next();
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                 // every wave is done reading the previous step's LDS image
         stage();
         __syncthreads();
-        if (kt + 1 < nk) {
-            advance();
-            fetch();                     // in flight during the MFMAs below
-        }
+        // 48 MFMAs in 6 groups of 8 = (k half, position pair), consecutive MFMAs alternating between two accumulators.
+        // A wave issues in order, so whatever it issues in a clump is time it cannot issue MFMAs: the 16 ds_read_b128
+        // of the next group's operands and the 12 buffer loads of K step kt+1 (all-invalid after the last step) are
+        // therefore placed one at a time behind individual MFMAs, and scheduling barriers pin that placement.
+        float4 fa[2][2], fb[2][2];
+        auto frag_one = [&](int g, int set, int i) {          // i = 0..3: a[0], b[0], a[1], b[1]
+            const int kb = (g / 3) * 8, xi = 2 * (g % 3) + (i >> 1);
+            if (i & 1) fb[set][i >> 1] = *reinterpret_cast<const float4*>(&Bs[xi * BN * LD + (b_off ^ kb)]);
+            else       fa[set][i >> 1] = *reinterpret_cast<const float4*>(&As[xi * BMT * LD + (a_off ^ kb)]);
+        };
 #pragma unroll
-        for (int kb = 0; kb < BK; kb += 8) {
+        for (int i = 0; i < 4; ++i) frag_one(0, 0, i);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int xi = 0; xi < P; ++xi) {
-                const float4 a = *reinterpret_cast<const float4*>(&As[xi * BMT * LD + a_off + kb]);
-                const float4 b = *reinterpret_cast<const float4*>(&Bs[xi * BN * LD + b_off + kb]);
-                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[xi], 0, 0, 0);
-                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[xi], 0, 0, 0);
-                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[xi], 0, 0, 0);
-                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[xi], 0, 0, 0);
+        for (int g = 0; g < 6; ++g) {
+            const int set = g & 1, x0 = 2 * (g % 3);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = i & 1, e = i >> 1;
+                const float av = e == 0 ? fa[set][j].x : e == 1 ? fa[set][j].y : e == 2 ? fa[set][j].z : fa[set][j].w;
+                const float bv = e == 0 ? fb[set][j].x : e == 1 ? fb[set][j].y : e == 2 ? fb[set][j].z : fb[set][j].w;
+                acc[x0 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[x0 + j], 0, 0, 0);
+                if (i < 4 && g + 1 < 6) frag_one(g + 1, set ^ 1, i);
+                if (i >= 4 && i < 6) fetch_one(2 * g + (i - 4));
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        fetch_next();
     }
     __syncthreads();                     // LDS becomes the epilogue slabs
 
@@ -273,8 +293,9 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
         return RPG_ERR_BAD_ARG;
     const int tw = (w + 3) / 4;
     const long M = (long)n * h * tw;
-    // 32-bit buffer offsets: a workgroup's 64 tiles span at most 65 images; U is addressed from its base
-    if (M >= (1L << 31) || (long)h * w * cin * 4 * 66 >= (1L << 31) || 6L * cout * 3 * cin * 4 >= (1L << 31))
+    // 32-bit buffer offsets: a workgroup's 64 tiles span at most 65 images (+ 3 rows of scalar offset); U is
+    // addressed from its base
+    if (M >= (1L << 31) || (long)h * w * cin * 4 * 67 >= (1L << 31) || 6L * cout * 3 * cin * 4 >= (1L << 31))
         return RPG_ERR_BAD_ARG;
     static bool attr = false;
     if (!attr) {
