@@ -199,7 +199,8 @@ int rpg_timing_read(double* ms, long long* launches, double* work);
 #define RPG_TUNE_GNN_SPLIT 5      /* 1: per-node precompute of the split concatenated-input Linears (default, needs
                                      the 26-tensor table) | 0: reference formulation (gathered 3-source GEMMs) */
 #define RPG_TUNE_BF16_BK 6        /* K step of the bf16 convolution kernel: 32 (default) | 64 */
-#define RPG_TUNE_WINOGRAD 4       /* 1: use u_wino43 where given (default) | 0: always the direct kernel */
+#define RPG_TUNE_WINOGRAD 4       /* 0: always the direct kernel | 1: use u_wino43 where given, kernel by size (default) |
+                                     2 / 3: as 1 but always the 4-wave (64 tiles) / 8-wave (128 tiles) Winograd kernel */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -110,12 +110,10 @@ extern "C" int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors
             float* Y = buf[(cur + 2) & 3];
             float* D = buf[(cur + 3) & 3];
             // conv1 3x3/stride + BN + ReLU
-            // Winograd needs (a) 32-bit buffer offsets and (b) enough 64-tile x 64-channel workgroups to occupy the chip:
-            // its K loop is not split, so a small grid is latency-bound (measured crossover vs the direct kernel with
-            // stream-K: ~128 workgroups = half the CUs; e.g. 8 images: layer3 117 us vs 47 us, layer4 216 us vs 63 us).
-            const long wino_blocks = (((long)n * ho * ((wo + 3) / 4) + 63) / 64) * ((c + 63) / 64);
-            const bool wino_fits = (long)hh * ww * (cin > c ? cin : c) * 4 * 66 < (1L << 31) && wino_blocks >= 128;
-            if (stride == 1 && tensors[ti + 3] && rpg::wino_enabled() && wino_fits)
+            // Winograd where it pays (rpg::wino_pays: addressable with 32-bit buffer offsets and enough workgroups)
+            const bool wino1 = stride == 1 && tensors[ti + 3] && rpg::wino_pays(n, hh, ww, cin, c);
+            const bool wino2 = tensors[ti + 7] && rpg::wino_pays(n, ho, wo, c, c);
+            if (wino1)
                 rc = rpg::launch_conv_wino(X, tensors[ti + 3], tensors[ti + 1], tensors[ti + 2], nullptr, T, n, hh, ww, cin,
                                            c, 1, s);
             else
@@ -130,7 +128,7 @@ extern "C" int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors
                 identity = D;
             }
             // conv2 3x3/1 + BN + identity + ReLU
-            if (tensors[ti + 7] && rpg::wino_enabled() && wino_fits)
+            if (wino2)
                 rc = rpg::launch_conv_wino(T, tensors[ti + 7], tensors[ti + 5], tensors[ti + 6], identity, Y, n, ho, wo, c, c,
                                            1, s);
             else

@@ -681,7 +681,7 @@ extern "C" int rpg_set_tuning(int key, int value) {
         case RPG_TUNE_STREAMK: g_streamk = value != 0; return RPG_OK;
         case RPG_TUNE_BF16_BK: if (value != 32 && value != 64) return RPG_ERR_BAD_ARG; rpg::bf16_set_bk(value); return RPG_OK;
         case RPG_TUNE_GNN_SPLIT: g_gnn_split = value != 0; return RPG_OK;
-        case RPG_TUNE_WINOGRAD: rpg::wino_set(value != 0); return RPG_OK;
+        case RPG_TUNE_WINOGRAD: if (value < 0 || value > 3) return RPG_ERR_BAD_ARG; rpg::wino_set(value); return RPG_OK;
         default: return RPG_ERR_BAD_ARG;
     }
 }

@@ -43,6 +43,9 @@ int launch_conv(const float* x, const float* w, const float* scale, const float*
 int launch_conv_wino(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
                      float* y, int n, int h, int w, int cin, int cout, int relu, hipStream_t s);
 bool wino_enabled();
+// true if the composite forward should route this 3x3/stride-1 convolution to launch_conv_wino (enabled, shape
+// addressable, and large enough that the un-split K loop is not latency-bound)
+bool wino_pays(int n, int h, int w, int cin, int cout);
 void wino_set(int on);
 // Gathered residual rows added in the epilogue: out[m] += res1[idx1[m]] (+ res2[idx2[m]]), row pitch ld.
 struct GatherRes {

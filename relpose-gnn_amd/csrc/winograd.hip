@@ -52,6 +52,62 @@ __device__ __forceinline__ float4 sub(const float4& x, const float4& y) {
     return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
 }
 
+// Epilogue of one wave: output transform of its 6 accumulators (lane-local: the MFMA C layout puts the same (tile,
+// cout) element of all 6 products in the same lane), then an LDS transpose to 16-byte row segments and the fused
+// BatchNorm / residual / ReLU / store, two of the four pixel columns at a time.  mw0 = first tile of the wave's 32,
+// nw0 = first output channel of its 32; slab = 64 x 36 floats of LDS private to the wave.
+__device__ __forceinline__ void wino43_epilogue(const f32x16 (&acc)[P], float* slab, int lane, int mw0, int nw0, int M,
+                                                int Tw, int W, int Cout, const Epi& ep) {
+    constexpr int EP = 32 + 4;                              // slab pitch: 32 channels + pad
+    const int c4 = lane & 7, pr = lane >> 3;                // 8 lanes cover a row's 32 channels; 8 rows per pass
+    const int nb = nw0 + 4 * c4;
+    const bool n_ok = nb < Cout;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
+    if (n_ok && ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + nb);
+    if (n_ok && ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + nb);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e];
+            float ya, yb;
+            if (half == 0) {
+                ya = acc[0][e] + m1 + m2 + m3 + m4;                     // y0
+                yb = (m1 - m2) + 2.f * (m3 - m4);                       // y1
+            } else {
+                ya = (m1 + m2) + 4.f * (m3 + m4);                       // y2
+                yb = (m1 - m2) + 8.f * (m3 - m4) + acc[5][e];           // y3
+            }
+            const int trow = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);  // tile within the wave's 32
+            slab[(2 * trow) * EP + (lane & 31)] = ya;
+            slab[(2 * trow + 1) * EP + (lane & 31)] = yb;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int prow = pr + 8 * it;                               // 0..63 = (tile, pixel-in-half)
+            const float4 v = *reinterpret_cast<const float4*>(&slab[prow * EP + 4 * c4]);
+            const int mt = mw0 + (prow >> 1);
+            if (mt < M && n_ok) {
+                const int tw = mt % Tw;
+                const int t = mt / Tw;                                  // = n*H + ho
+                const int wo = 4 * tw + 2 * half + (prow & 1);
+                if (wo < W) {
+                    const size_t o = ((size_t)t * W + wo) * Cout + nb;
+                    float4 rs = f4zero();
+                    if (ep.residual) rs = *reinterpret_cast<const float4*>(ep.residual + o);
+                    float4 y;
+                    y.x = v.x * sc.x + sh.x + rs.x; y.y = v.y * sc.y + sh.y + rs.y;
+                    y.z = v.z * sc.z + sh.z + rs.z; y.w = v.w * sc.w + sh.w + rs.w;
+                    if (ep.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+                    *reinterpret_cast<float4*>(ep.out + o) = y;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // x [n][H][W][Cin] -> y [n][H][W][Cout];  U [6][Cout][3][Cin];  M = n*H*Tw tiles, Tw = ceil(W/4)
 __global__ __launch_bounds__(NT, 2) void wino43_conv_kernel(const float* __restrict__ x, const float* __restrict__ U,
                                                          int H, int W, int Cin, int Cout, int Tw, int M, Epi ep,
@@ -206,56 +262,237 @@ __global__ __launch_bounds__(NT, 2) void wino43_conv_kernel(const float* __restr
     }
     __syncthreads();                     // LDS becomes the epilogue slabs
 
-    // ---- epilogue: output transform (lane-local), then LDS transpose -> 16-byte row segments
-    constexpr int EP = 32 + 4;                              // slab pitch: 32 channels + pad
-    float* slab = lds + wave * (64 * EP);                   // 64 pixel rows (32 tiles x 2 pixels) per half
-    const int c4 = lane & 7, pr = lane >> 3;                // 8 lanes cover a row's 32 channels; 8 rows per pass
-    const int nb = n0 + wn * 32 + 4 * c4;
-    const bool n_ok = nb < Cout;
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
-    if (n_ok && ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + nb);
-    if (n_ok && ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + nb);
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e];
-            float ya, yb;
-            if (half == 0) {
-                ya = acc[0][e] + m1 + m2 + m3 + m4;                     // y0
-                yb = (m1 - m2) + 2.f * (m3 - m4);                       // y1
-            } else {
-                ya = (m1 + m2) + 4.f * (m3 + m4);                       // y2
-                yb = (m1 - m2) + 8.f * (m3 - m4) + acc[5][e];           // y3
-            }
-            const int trow = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);  // tile within the wave's 32
-            slab[(2 * trow) * EP + (lane & 31)] = ya;
-            slab[(2 * trow + 1) * EP + (lane & 31)] = yb;
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int prow = pr + 8 * it;                               // 0..63 = (tile, pixel-in-half)
-            const float4 v = *reinterpret_cast<const float4*>(&slab[prow * EP + 4 * c4]);
-            const int mt = m0 + wm * 32 + (prow >> 1);
-            if (mt < M && n_ok) {
-                const int tw = mt % Tw;
-                const int t = mt / Tw;                                  // = n*H + ho
-                const int wo = 4 * tw + 2 * half + (prow & 1);
-                if (wo < W) {
-                    const size_t o = ((size_t)t * W + wo) * Cout + nb;
-                    float4 rs = f4zero();
-                    if (ep.residual) rs = *reinterpret_cast<const float4*>(ep.residual + o);
-                    float4 y;
-                    y.x = v.x * sc.x + sh.x + rs.x; y.y = v.y * sc.y + sh.y + rs.y;
-                    y.z = v.z * sc.z + sh.z + rs.z; y.w = v.w * sc.w + sh.w + rs.w;
-                    if (ep.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
-                    *reinterpret_cast<float4*>(ep.out + o) = y;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+    wino43_epilogue(acc, lds + wave * (64 * 36), lane, m0 + wm * 32, n0 + wn * 32, M, Tw, W, Cout, ep);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The large-problem kernel: 8 waves on 128 tiles (= 512 output pixels) x 64 output channels, TWO LDS images of a K
+// step (2 x 72 KB, one workgroup = two waves per SIMD per CU) and ONE barrier per K step.
+//
+// Measured on gfx950 (tools/probes/mfma_shadow_probe.hip): v_mfma_f32_32x32x2_f32 and ordinary VALU instructions of a
+// SIMD do NOT overlap (each VALU op costs ~4.4 cycles of matrix-pipe time with two waves per SIMD, ~8 with one), while
+// ds_read / ds_write / buffer_load issue mostly hides behind MFMAs, and a wave issues in order.  Hence:
+//   * nothing runs in a separate phase: the 9 stage pieces of K step kt+1 (-> the other image), the 9 buffer loads
+//     of K step kt+2 and the 24 operand reads of step kt are placed one at a time behind individual MFMAs
+//     (scheduling barriers pin the placement), so a wave never stops issuing MFMAs except at the one barrier;
+//   * VALU work per K step is cut to the input transform itself (24 packed FMAs / adds): all addressing that depends
+//     on the lane is K-invariant (effective offsets are refreshed only when the kernel row or the channel tail
+//     changes, a few times per kernel), the K step goes into the scalar offset of the buffer instruction, and the
+//     K loop is unrolled by two so the image toggles at compile time.
+// Staging: thread t stages A row t>>2 (128 tiles), k-slot t&3: 6 pixels -> 6 transformed chunks; and U row (t>>2)&63
+// of positions 3*(t>>8) .. +2: 3 chunks.  Wave w owns tiles 32*(w>>1).., channels 32*(w&1)..
+constexpr int NT8 = 512, BMT8 = 128;
+constexpr int A8_FLOATS = P * BMT8 * LD, IMG8_FLOATS = A8_FLOATS + B_FLOATS;      // 12288 + 6144 floats = 72 KB
+constexpr int LDS8_BYTES = 2 * IMG8_FLOATS * (int)sizeof(float);                  // 147,456
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct F4 { f32x2 lo, hi; };             // a 16-byte chunk as two packed pairs
+__device__ __forceinline__ F4 to_f4(const float4& v) { return F4{f32x2{v.x, v.y}, f32x2{v.z, v.w}}; }
+__device__ __forceinline__ float4 to_float4(const F4& v) { return make_float4(v.lo.x, v.lo.y, v.hi.x, v.hi.y); }
+// Packed f32 VALU written as instructions: beside MFMAs hipcc splits packed f32 arithmetic into scalar halves (twice
+// the instructions), which is the wrong trade here because VALU time is not hidden behind the f32 MFMAs.  The scale
+// is an inline constant (+-2, +-4) broadcast to both halves.
+#define RPG_PK_FMA(NAME, CONST)                                                                               \
+    __device__ __forceinline__ f32x2 NAME(f32x2 x, f32x2 y) {                                                 \
+        f32x2 r;                                                                                              \
+        asm("v_pk_fma_f32 %0, %1, " CONST ", %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(y));               \
+        return r;                                                                                             \
     }
+RPG_PK_FMA(pk_fma_p4, "4.0")
+RPG_PK_FMA(pk_fma_m4, "-4.0")
+RPG_PK_FMA(pk_fma_p2, "2.0")
+RPG_PK_FMA(pk_fma_m2, "-2.0")
+#undef RPG_PK_FMA
+__device__ __forceinline__ f32x2 pk_add(f32x2 x, f32x2 y) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 x, f32x2 y) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+#define RPG_F4_OP(NAME, OP) \
+    __device__ __forceinline__ F4 NAME(const F4& x, const F4& y) { return F4{OP(x.lo, y.lo), OP(x.hi, y.hi)}; }
+RPG_F4_OP(fma4_p4, pk_fma_p4)   // 4 x + y
+RPG_F4_OP(fma4_m4, pk_fma_m4)   // -4 x + y
+RPG_F4_OP(fma4_p2, pk_fma_p2)
+RPG_F4_OP(fma4_m2, pk_fma_m2)
+RPG_F4_OP(add4, pk_add)
+RPG_F4_OP(sub4, pk_sub)
+#undef RPG_F4_OP
+
+__global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restrict__ x, const float* __restrict__ U, int H,
+                                                          int W, int Cin, int Cout, int Tw, int M, Epi ep, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int K = 3 * Cin;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r8 = nwg & 7;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+    const int m0 = (tile / tiles_n) * BMT8;
+    const int n0 = (tile % tiles_n) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int row = tid >> 2, slot = tid & 3;          // A: tile-row `row` (0..127), k-slot `slot`
+    const int brow = row & 63, bhalf = tid >> 8;       // B: channel-row brow, positions 3*bhalf .. 3*bhalf+2
+
+    // ---- K-invariant staging addresses (see wino43_conv_kernel for the buffer-load conventions)
+    const int n_first = (m0 / Tw) / H;
+    const size_t img_floats = (size_t)H * W * Cin;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x + n_first * img_floats) - (size_t)W * Cin, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, 0x7fffffff, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned va[P], va_eff[P];
+    unsigned rowbits = 0;                 // bit kh set <=> image row ho-1+kh exists (and the tile itself does)
+    {
+        const int m = m0 + row;
+        int img_off = 0, ho = 0, wi0 = -(1 << 24);
+        if (m < M) {
+            const int tw = m % Tw;
+            const int t = m / Tw;
+            ho = t % H;
+            img_off = (t / H - n_first) * (int)img_floats;
+            wi0 = 4 * tw - 1;
+            rowbits = (ho > 0 ? 1u : 0u) | 2u | (ho < H - 1 ? 4u : 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int wi = wi0 + j;
+            va[j] = (unsigned)wi < (unsigned)W ? 4u * (unsigned)(img_off + (ho * W + wi) * Cin + 4 * slot) : OOB;
+        }
+    }
+    const unsigned ustride_b = (unsigned)Cout * K * 4u;
+    const unsigned vb = n0 + brow < Cout ? 4u * (unsigned)((n0 + brow) * K + 4 * slot) + 3u * bhalf * ustride_b : OOB;
+    unsigned vb_eff;
+    const int nk = 3 * ((Cin + BK - 1) / BK);
+    int f_kt = 0, f_kh = 0, f_c0 = 0;     // the K step the next fetches load (wave-uniform)
+    auto refresh = [&]() {                // effective offsets of K step f_kt: row border, channel tail, past the end
+        asm volatile("" ::: "memory");    // keeps this a (rarely taken) branch: if-converted it is 11 VALU per K step
+        const bool cv = f_kt < nk && f_c0 + 4 * slot < Cin;
+        const bool rv = cv && ((rowbits >> f_kh) & 1u);
+#pragma unroll
+        for (int j = 0; j < P; ++j) va_eff[j] = rv ? va[j] : OOB;
+        vb_eff = cv ? vb : OOB;
+    };
+    refresh();
+
+    float4 d[P], ub[3];
+    auto fetch_one = [&](int i) {         // i = 0..8: pixels 0..5, then this thread's 3 U positions
+        if (i < P) {
+            const unsigned sa = 4u * (unsigned)(f_kh * W * Cin + f_c0);
+            d[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, va_eff[i], sa, 0));
+        } else {
+            const unsigned sb = 4u * (unsigned)(f_kh * Cin + f_c0) + (unsigned)(i - P) * ustride_b;
+            ub[i - P] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, vb_eff, sb, 0));
+        }
+    };
+    auto fetch_next = [&]() {
+        ++f_kt;
+        f_c0 += BK;
+        if (f_c0 >= Cin) { f_c0 = 0; ++f_kh; }
+        if (f_c0 == 0 || f_c0 + BK > Cin || f_kt >= nk) refresh();        // rare: 3 + 2 times for Cin % 16 == 0
+    };
+
+    // stage_one(p, img), p = 0..8: piece p of the K step held in d / ub -> LDS image img (float offset).  p < 6: the
+    // input transform V[p] = BT d (BT of F(4,3), points 0, +-1, +-2, inf) in 12 packed FMA / add per 4 channels;
+    // p >= 6: U chunk p-6.  Chunk (row, slot) lives at slot ^ ((row >> 2) & 3): conflict-free ds_write_b128 and
+    // ds_read_b128 with an unpadded 64-byte pitch.
+    const int st_a = row * LD + 4 * (slot ^ ((row >> 2) & 3));
+    const int st_b = A8_FLOATS + (3 * bhalf) * BN * LD + brow * LD + 4 * (slot ^ ((brow >> 2) & 3));
+    auto stage_one = [&](int p, int img) {
+        if (p >= P) {
+            *reinterpret_cast<float4*>(lds + img + st_b + (p - P) * BN * LD) = ub[p - P];
+            return;
+        }
+        // r = d4 - d2 and t = d3 - d1 are shared by four of the six outputs
+        const F4 d0 = to_f4(d[0]), d1 = to_f4(d[1]), d2 = to_f4(d[2]), d3 = to_f4(d[3]), d4 = to_f4(d[4]), d5 = to_f4(d[5]);
+        F4 v;
+        if (p == 0) v = fma4_p4(sub4(d0, d2), sub4(d4, d2));                   // 4 d0 - 5 d2 + d4 = 4 (d0 - d2) + r
+        else if (p == 5) v = fma4_m4(sub4(d3, d1), sub4(d5, d3));              // 4 d1 - 5 d3 + d5 = -4 t + (d5 - d3)
+        else if (p <= 2) {
+            const F4 sx = fma4_m4(d2, d4);                                     // d4 - 4 d2
+            const F4 tx = fma4_m4(d1, d3);                                     // d3 - 4 d1
+            v = p == 1 ? add4(sx, tx) : sub4(sx, tx);
+        } else {
+            const F4 r = sub4(d4, d2), t = sub4(d3, d1);
+            v = p == 3 ? fma4_p2(t, r) : fma4_m2(t, r);                        // r +- 2 t
+        }
+        *reinterpret_cast<float4*>(lds + img + st_a + p * BMT8 * LD) = to_float4(v);
+    };
+
+    f32x16 acc[P];
+#pragma unroll
+    for (int xi = 0; xi < P; ++xi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[xi][e] = 0.f;
+
+    const int rsw = 4 * ((lane >> 5) ^ ((lane >> 2) & 3));            // logical chunk (lane>>5) [+2 for kb = 8: ^ 8 floats]
+    const int a_off = (wm * 32 + (lane & 31)) * LD + rsw;
+    const int b_off = A8_FLOATS + (wn * 32 + (lane & 31)) * LD + rsw;
+    float4 fa[2][2], fb[2][2];
+    auto frag_one = [&](int g, int set, int i, int img) {             // i = 0..3: a[0], b[0], a[1], b[1]
+        const int kb = (g / 3) * 8, xi = 2 * (g % 3) + (i >> 1);
+        if (i & 1) fb[set][i >> 1] = *reinterpret_cast<const float4*>(&lds[img + xi * BN * LD + (b_off ^ kb)]);
+        else       fa[set][i >> 1] = *reinterpret_cast<const float4*>(&lds[img + xi * BMT8 * LD + (a_off ^ kb)]);
+    };
+    // one K step on image `cur` (compile-time float offset), staging step kt+1 into `nxt`, fetching step kt+2:
+    //   groups 0-5, MFMAs 0-3: the 4 operand reads of the next group (group 5: of the next K step's group 0, from nxt)
+    //   groups 0-2, MFMAs 4-7: stage pieces 0..8 -> nxt        groups 3-5, MFMAs 4-7: buffer loads 0..8
+    //   barrier after group 4: every wave has written nxt and issued its last reads of cur
+    auto kstep = [&](int cur, int nxt) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            const int set = g & 1, x0 = 2 * (g % 3);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = i & 1, e = i >> 1;
+                const float av = e == 0 ? fa[set][j].x : e == 1 ? fa[set][j].y : e == 2 ? fa[set][j].z : fa[set][j].w;
+                const float bv = e == 0 ? fb[set][j].x : e == 1 ? fb[set][j].y : e == 2 ? fb[set][j].z : fb[set][j].w;
+                acc[x0 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[x0 + j], 0, 0, 0);
+                if (i < 4) {
+                    if (g < 5) frag_one(g + 1, set ^ 1, i, cur);
+                    else frag_one(0, 0, i, nxt);
+                } else {
+                    const int s = 4 * (g % 3) + (i - 4);              // 0..11, pieces 0..8 used
+                    if (s < 9) {
+                        if (g < 3) stage_one(s, nxt);
+                        else fetch_one(s);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g == 4) {
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        fetch_next();
+    };
+
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fetch_one(i);
+    fetch_next();
+#pragma unroll
+    for (int p = 0; p < 9; ++p) stage_one(p, 0);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fetch_one(i);
+    fetch_next();
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) frag_one(0, 0, i, 0);
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        kstep(0, IMG8_FLOATS);
+        kstep(IMG8_FLOATS, 0);
+    }
+    if (kt < nk) kstep(0, IMG8_FLOATS);
+    __syncthreads();                     // LDS becomes the epilogue slabs
+    wino43_epilogue(acc, lds + wave * (64 * 36), lane, m0 + wm * 32, n0 + wn * 32, M, Tw, W, Cout, ep);
 }
 
 // U[xi][co][kh][c] = sum_j G[xi][j] * w[co][kh][j][c], evaluated in double and rounded once.
@@ -276,7 +513,7 @@ __global__ __launch_bounds__(NT) void wino43_weights_kernel(const float* __restr
     for (int xi = 0; xi < 6; ++xi) U[xi * plane + i] = (float)u[xi];
 }
 
-int g_wino = 1;
+int g_wino = 1;                          // RPG_TUNE_WINOGRAD: 0 off | 1 auto | 2 always the 4-wave kernel | 3 always the 8-wave kernel
 
 }  // namespace
 
@@ -284,6 +521,16 @@ namespace rpg {
 
 bool wino_enabled() { return g_wino != 0; }
 void wino_set(int on) { g_wino = on; }
+
+// Winograd needs (a) 32-bit buffer offsets (checked again by the launcher) and (b) enough 64-tile x 64-channel units
+// of work to occupy the chip: its K loop is not split, so a small grid is latency-bound (measured crossover vs the
+// direct kernel with stream-K: ~128 workgroups = half the CUs; e.g. 8 images: layer3 117 us vs 47 us, layer4 216 vs 63).
+bool wino_pays(int n, int h, int w, int cin, int cout) {
+    if (!g_wino || (cin & 3) || (cout & 3)) return false;
+    const long tiles = (long)n * h * ((w + 3) / 4);
+    const long blocks = ((tiles + BMT - 1) / BMT) * ((cout + BN - 1) / BN);
+    return blocks >= 128 && (long)h * w * cin * 4 * 67 < (1L << 31) && 6L * cout * 3 * cin * 4 < (1L << 31);
+}
 
 int launch_conv_wino(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
                      float* y, int n, int h, int w, int cin, int cout, int relu, hipStream_t s) {
@@ -303,10 +550,25 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr = true;
     }
-    const int tm = (int)((M + BMT - 1) / BMT), tn = (cout + BN - 1) / BN;
+    const int tn = (cout + BN - 1) / BN;
     Epi ep{scale, shift, residual, y, relu};
     const int slot = timing_begin(RPG_TIMER_CONV_WINO, s);
-    hipLaunchKernelGGL(wino43_conv_kernel, dim3(tm * tn), dim3(NT), LDS_BYTES, s, x, u, h, w, cin, cout, tw, (int)M, ep, tn);
+    const long tm8 = (M + BMT8 - 1) / BMT8;
+    const bool fits8 = (long)h * w * cin * 4 * 131 < (1L << 31);     // a workgroup's 128 tiles span at most 129 images
+    if (fits8 && (g_wino == 3 || (g_wino == 1 && tm8 * tn >= 64))) {
+        // large problems (or RPG_TUNE_WINOGRAD = 3): 8 waves on 128 tiles, double-buffered
+        static bool attr8 = false;
+        if (!attr8) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino43_conv8_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
+            attr8 = true;
+        }
+        hipLaunchKernelGGL(wino43_conv8_kernel, dim3((unsigned)(tm8 * tn)), dim3(NT8), LDS8_BYTES, s, x, u, h, w, cin, cout,
+                           tw, (int)M, ep, tn);
+    } else {
+        const int tm = (int)((M + BMT - 1) / BMT);
+        hipLaunchKernelGGL(wino43_conv_kernel, dim3(tm * tn), dim3(NT), LDS_BYTES, s, x, u, h, w, cin, cout, tw, (int)M, ep, tn);
+    }
     timing_end(slot, 2.0 * (double)n * h * w * cout * 9.0 * cin, s);      // algorithmic (direct-convolution) FLOP
     RPG_CHECK_LAUNCH("conv3x3_wino43");
     return RPG_OK;

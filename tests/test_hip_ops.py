@@ -289,8 +289,10 @@ def test_knn_graph(dev, sizes, k, d):
     (4, 14, 14, 256, 256, True, True),     # layer3: 14 -> 4 tiles per row (12.5 % padding)
     (4, 7, 7, 512, 512, True, True),       # layer4: 7 -> 2 tiles per row
     (2, 256 // 8, 341 // 8 + 1, 128, 128, True, True),   # odd width from the 256x341 evaluation shape (32x43)
+    (40, 12, 9, 20, 68, True, True),       # many images per 128-tile workgroup, channel tail (Cin % 16 = 4), odd K-step count
 ])
-def test_conv3x3_winograd(dev, n, h, w, cin, cout, res, relu):
+@pytest.mark.parametrize("kernel", [2, 3], ids=["wave4", "wave8"])
+def test_conv3x3_winograd(dev, n, h, w, cin, cout, res, relu, kernel):
     """1-D Winograd F(4,3) convolution vs F.conv2d; tolerance 2e-5 (the transforms cost ~2.5x the rounding error of
     the direct kernel per layer: measured in tools, still 5x below the per-op bar used elsewhere x 2)."""
     from relpose_gnn_amd import ops
@@ -312,8 +314,12 @@ def test_conv3x3_winograd(dev, n, h, w, cin, cout, res, relu):
                       [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
     u_ref = torch.einsum("xj,ohjc->xohc", G, wt.permute(0, 2, 3, 1).double()).float()
     assert torch.allclose(u.cpu(), u_ref, rtol=2e-7, atol=1e-9)
-    y = ops.conv3x3_wino43_bn_act_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), u, scale.to(dev), shift.to(dev),
-                                       None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev), relu=relu)
+    ops.set_tuning(ops.TUNE_WINOGRAD, kernel)          # 2: the 4-wave / 64-tile kernel, 3: the 8-wave / 128-tile one
+    try:
+        y = ops.conv3x3_wino43_bn_act_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), u, scale.to(dev), shift.to(dev),
+                                           None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev), relu=relu)
+    finally:
+        ops.set_tuning(ops.TUNE_WINOGRAD, 1)
     err = rel_err(y.cpu().permute(0, 3, 1, 2), ref)
     assert err < 2e-5, err
 

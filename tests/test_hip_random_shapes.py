@@ -53,8 +53,9 @@ def test_random_conv_direct(dev, case):
     assert rel_err(y.cpu().permute(0, 3, 1, 2), ref) < 1e-5, (kh, kw, stride, pad, cin, cout, n, h, w)
 
 
+@pytest.mark.parametrize("kernel", [2, 3], ids=["wave4", "wave8"])
 @pytest.mark.parametrize("case", range(16))
-def test_random_conv_winograd(dev, case):
+def test_random_conv_winograd(dev, case, kernel):
     from relpose_gnn_amd import ops
     rng = random.Random(2000 + case)
     cin, cout = 4 * rng.randint(1, 40), 4 * rng.randint(1, 50)
@@ -72,8 +73,12 @@ def test_random_conv_winograd(dev, case):
     if relu:
         ref = F.relu(ref)
     u = ops.wino43_transform_weights(wt.permute(0, 2, 3, 1).contiguous().to(dev))
-    y = ops.conv3x3_wino43_bn_act_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), u, scale.to(dev), shift.to(dev),
-                                       None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev), relu=relu)
+    ops.set_tuning(ops.TUNE_WINOGRAD, kernel)          # both Winograd kernels on every shape (1 = choose by size)
+    try:
+        y = ops.conv3x3_wino43_bn_act_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), u, scale.to(dev), shift.to(dev),
+                                           None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev), relu=relu)
+    finally:
+        ops.set_tuning(ops.TUNE_WINOGRAD, 1)
     assert rel_err(y.cpu().permute(0, 3, 1, 2), ref) < 2e-5, (cin, cout, n, h, w)
 
 
