@@ -231,6 +231,7 @@ extern "C" int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, c
         g.a[0] = a0; g.idx[0] = i0; g.ld[0] = w0; g.width[0] = w0;
         g.a[1] = a1; g.idx[1] = i1; g.ld[1] = w1; g.width[1] = w1;
         g.a[2] = a2; g.idx[2] = i2; g.ld[2] = w2; g.width[2] = w2;
+        for (int i = 0; i < 3; ++i) g.rows[i] = g.idx[i] ? (n > e ? n : e) : 0;       // node / edge ids index n- or e-row arrays
         return rpg::launch_linear(g, tensors[wt], tensors[wt + 1], residual, out, m, n_out, relu, s);
     };
 

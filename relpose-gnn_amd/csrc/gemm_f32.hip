@@ -61,6 +61,7 @@ struct ConvArgs {
 
 template <int R, int BK>
 struct ConvLoader {
+    static constexpr bool kBuffer = false;
     static constexpr int SLOTS = BK / 4, ROWS_PER_PASS = NTHREADS / SLOTS;
     const float* img[R];
     int hi0[R], wi0[R];
@@ -119,6 +120,7 @@ struct GatherArgs {
 
 template <int R, int BK>
 struct GatherLoader {
+    static constexpr bool kBuffer = false;
     static constexpr int SLOTS = BK / 4, ROWS_PER_PASS = NTHREADS / SLOTS;
     const float* r0p[R];
     const float* r1p[R];
@@ -159,6 +161,146 @@ struct GatherLoader {
         }
     }
     __device__ __forceinline__ void advance() { k += BK; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Buffer-load loaders (tile_mainloop_b).  Measured on gfx950 (tools/probes/mfma_shadow_probe.hip): VALU instructions
+// do not overlap with f32 MFMAs on a SIMD and a wave issues in order, so per-step address arithmetic and branchy
+// conditional loads come straight out of matrix-pipe time.  These loaders keep everything lane-dependent K-invariant:
+// a row is a 32-bit byte offset into a raw buffer resource (0x80000000 = out of range = the hardware returns zeros,
+// which serves both ragged tiles and convolution padding), the K position goes into the instruction's scalar offset,
+// and the offsets are rebuilt only when the source segment / kernel tap changes (a rarely taken branch).
+// Preconditions (checked on the host, else the general loaders above are used): every segment length (gather widths,
+// Cin) is a multiple of BK, and the offsets fit in 32 bits.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+template <int R, int BK>
+struct ConvLoaderB {
+    static constexpr bool kBuffer = true;
+    static constexpr int SLOTS = BK / 4, ROWS_PER_PASS = NTHREADS / SLOTS;
+    __amdgpu_buffer_rsrc_t rs;
+    int base[R], hi0[R], wi0[R];      // element offset of the row's image (relative to the tile's first image); -1 = no row
+    int H, W, Cin, KW, slot4;
+    unsigned voff[R];
+    int kh, kw, c0, k0, kend;         // wave-uniform position of the next fetch
+
+    __device__ __forceinline__ void init(const ConvArgs& a, int m0, int M, int tid, int kbase, int kend_) {
+        H = a.H; W = a.W; Cin = a.Cin; KW = a.KW; slot4 = 4 * (tid % SLOTS); kend = kend_;
+        const int r0 = tid / SLOTS;
+        const int n_first = m0 / (a.Ho * a.Wo);
+        const int img = a.H * a.W * a.Cin;
+        rs = make_rsrc(a.x + (size_t)n_first * img);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int m = m0 + r0 + ROWS_PER_PASS * j;
+            base[j] = -1; hi0[j] = 0; wi0[j] = 0;
+            if (m < M) {
+                const int wo = m % a.Wo;
+                const int t = m / a.Wo;
+                base[j] = (t / a.Ho - n_first) * img;
+                hi0[j] = (t % a.Ho) * a.stride - a.pad;
+                wi0[j] = wo * a.stride - a.pad;
+            }
+        }
+        k0 = kbase;
+        c0 = kbase % Cin;
+        const int t = kbase / Cin;
+        kw = t % KW;
+        kh = t / KW;
+        refresh();
+    }
+    __device__ __forceinline__ void refresh() {           // offsets of tap (kh, kw); everything invalid past kend
+        asm volatile("");                                  // keeps the callers' branch: if-converted this is ~8 VALU / row
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+            const bool ok = base[j] >= 0 && k0 < kend && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+            voff[j] = ok ? 4u * (unsigned)(base[j] + (hi * W + wi) * Cin + slot4) : OOB;
+        }
+    }
+    __device__ __forceinline__ float4 fetch_one(int j) const { return buf_ld4(rs, voff[j], 4u * (unsigned)c0); }
+    __device__ __forceinline__ void advance() {
+        k0 += BK;
+        c0 += BK;
+        if (c0 >= Cin || k0 >= kend) {
+            if (c0 >= Cin) { c0 = 0; if (++kw == KW) { kw = 0; ++kh; } }
+            refresh();
+        }
+    }
+};
+
+template <int R, int BK>
+struct GatherLoaderB {
+    static constexpr bool kBuffer = true;
+    static constexpr int SLOTS = BK / 4, ROWS_PER_PASS = NTHREADS / SLOTS;
+    const float* p0;
+    const float* p1;
+    const float* p2;
+    __amdgpu_buffer_rsrc_t rs;             // resource of the current segment (rebuilt from the pointer in refresh)
+    unsigned off0[R], off1[R], off2[R], voff[R];
+    int w0, w01, k0, kend, seg_begin, seg_end;
+
+    __device__ __forceinline__ void init(const GatherArgs& a, int m0, int M, int tid, int kbase, int kend_) {
+        w0 = a.w0; w01 = a.w01; kend = kend_;
+        const int slot4 = 4 * (tid % SLOTS), r0 = tid / SLOTS;
+        p0 = a.a[0];
+        p1 = a.a[1] ? a.a[1] : a.a[0];
+        p2 = a.a[2] ? a.a[2] : a.a[0];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int m = m0 + r0 + ROWS_PER_PASS * j;
+            off0[j] = off1[j] = off2[j] = OOB;
+            if (m < M) {
+                const int64_t i0 = a.idx[0] ? a.idx[0][m] : (int64_t)m;
+                off0[j] = 4u * (unsigned)(i0 * a.ld[0] + slot4);
+                if (a.a[1]) {
+                    const int64_t i1 = a.idx[1] ? a.idx[1][m] : (int64_t)m;
+                    off1[j] = 4u * (unsigned)(i1 * a.ld[1] + slot4);
+                }
+                if (a.a[2]) {
+                    const int64_t i2 = a.idx[2] ? a.idx[2][m] : (int64_t)m;
+                    off2[j] = 4u * (unsigned)(i2 * a.ld[2] + slot4);
+                }
+            }
+        }
+        k0 = kbase;
+        refresh();
+    }
+    __device__ __forceinline__ void refresh() {           // the segment holding k0; everything invalid past kend
+        asm volatile("");
+        const float* p;
+        if (k0 < w0) {
+            p = p0; seg_begin = 0; seg_end = w0;
+#pragma unroll
+            for (int j = 0; j < R; ++j) voff[j] = off0[j];
+        } else if (k0 < w01) {
+            p = p1; seg_begin = w0; seg_end = w01;
+#pragma unroll
+            for (int j = 0; j < R; ++j) voff[j] = off1[j];
+        } else {
+            p = p2; seg_begin = w01; seg_end = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < R; ++j) voff[j] = off2[j];
+        }
+        rs = make_rsrc(p);
+        if (k0 >= kend) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) voff[j] = OOB;
+        }
+    }
+    __device__ __forceinline__ float4 fetch_one(int j) const { return buf_ld4(rs, voff[j], 4u * (unsigned)(k0 - seg_begin)); }
+    __device__ __forceinline__ void advance() {
+        k0 += BK;
+        if (k0 >= seg_end || k0 >= kend) refresh();
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -256,6 +398,105 @@ __device__ __forceinline__ void tile_mainloop(const Args& args, const float* __r
         if (more) stage(cur ^ 1);
         __syncthreads();
     }
+}
+
+// The same contract as tile_mainloop for the buffer loaders, with every non-MFMA instruction placed behind an
+// individual MFMA (scheduling barriers pin the placement) so that a wave never stops issuing MFMAs except at the one
+// barrier per K step.  A step is BK/8 groups of FM*FN*4 MFMAs; behind the first FM+FN MFMAs of a group go the operand
+// reads of the next group (last group: of the next step's first group, from the other LDS image), behind the others
+// first the RA+RW stage writes of step kt+1 (data loaded during step kt-1), then the RA+RW buffer loads of step kt+2
+// into the same registers.  The barrier sits before the last group: by then every wave has written image kt+1 and
+// issued its last reads of image kt.
+template <int BM, int BN, int WM, int WN, int BK, template <int, int> class Loader, class Args>
+__device__ __forceinline__ void tile_mainloop_b(const Args& args, const float* __restrict__ Wt, int ldw, int M, int N,
+                                                int K, int m0, int n0, int ks, int ke, float* lds,
+                                                f32x16 (&acc)[Tile<BM, BN, WM, WN, BK>::FM][Tile<BM, BN, WM, WN, BK>::FN]) {
+    using T = Tile<BM, BN, WM, WN, BK>;
+    constexpr int LDS_LD = T::LDS_LD, ROWS_PER_PASS = T::ROWS_PER_PASS, FM = T::FM, FN = T::FN, RA = T::RA, RW = T::RW;
+    constexpr int KB = BK / 8, G = FM * FN * 4, NR = FM + FN, NJ = RA + RW, SPARE = G - NR;
+    static_assert(KB >= 2 && (KB & 1) == 0, "operand register sets alternate per group");
+    static_assert((KB - 1) * SPARE >= NJ && KB * SPARE >= 2 * NJ, "not enough MFMAs to hide the staging behind");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int slot = tid % T::SLOTS, srow = tid / T::SLOTS;
+    const int kend = ke * BK;
+
+    Loader<RA, BK> la;
+    la.init(args, m0, M, tid, ks * BK, kend);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(Wt);
+    unsigned woff[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+        const int n = n0 + srow + ROWS_PER_PASS * j;
+        woff[j] = n < N ? 4u * (unsigned)(n * ldw + 4 * slot) : OOB;
+    }
+    int kw_ = ks * BK;                 // wave-uniform K position of the next W fetch
+    float4 rr[NJ];                     // staging registers: A rows 0..RA-1, then W rows
+    auto load_job = [&](int q) {
+        if (q < RA) rr[q] = la.fetch_one(q);
+        else rr[q] = buf_ld4(rsw, kw_ < kend ? woff[q - RA] : OOB, 4u * (unsigned)kw_);
+    };
+    auto next_k = [&]() { la.advance(); kw_ += BK; };
+    const int st_off = srow * LDS_LD + 4 * slot;
+    auto write_job = [&](int q, int img) {
+        const int r = q < RA ? ROWS_PER_PASS * q : BM + ROWS_PER_PASS * (q - RA);
+        *reinterpret_cast<float4*>(&lds[img + st_off + r * LDS_LD]) = rr[q];
+    };
+    const int a_off = (wm * FM * 32 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
+    const int b_off = (BM + wn * FN * 32 + (lane & 31)) * LDS_LD + 4 * (lane >> 5);
+    float4 fr[2][NR];                  // operand fragments: [set][a_0..a_FM-1, b_0..b_FN-1]
+    auto read_job = [&](int set, int r, int g, int img) {
+        const int off = (r < FM ? a_off + r * 32 * LDS_LD : b_off + (r - FM) * 32 * LDS_LD) + 8 * g;
+        fr[set][r] = *reinterpret_cast<const float4*>(&lds[img + off]);
+    };
+    auto comp = [](const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; };
+    auto kstep = [&](int cur, int nxt) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < KB; ++g) {
+            const int set = g & 1;
+#pragma unroll
+            for (int ms = 0; ms < G; ++ms) {
+                const int c = ms / (FM * FN), i = (ms / FN) % FM, j = ms % FN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(fr[set][i], c), comp(fr[set][FM + j], c), acc[i][j], 0, 0, 0);
+                if (ms < NR) {
+                    if (g + 1 < KB) read_job(set ^ 1, ms, g + 1, cur);
+                    else read_job(0, ms, 0, nxt);
+                } else {
+                    const int q = g * SPARE + (ms - NR);
+                    if (q < NJ) write_job(q, nxt);
+                    else if (q < 2 * NJ) load_job(q - NJ);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g == KB - 2) {
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        next_k();
+    };
+
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) load_job(q);
+    next_k();
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) write_job(q, 0);
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) load_job(q);
+    next_k();
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) read_job(0, r, 0, 0);
+    const int nsteps = ke - ks;
+    int kt = 0;
+    for (; kt + 1 < nsteps; kt += 2) {
+        kstep(0, T::STAGE);
+        kstep(T::STAGE, 0);
+    }
+    if (kt < nsteps) kstep(0, T::STAGE);
+    __syncthreads();
 }
 
 // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).
@@ -371,7 +612,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tile_kernel(Args args, const fl
     const int n0 = (tile % tiles_n) * BN;
     f32x16 acc[T::FM][T::FN];
     zero_acc(acc);
-    tile_mainloop<BM, BN, WM, WN, BK, Loader, Args>(args, Wt, ldw, M, N, K, m0, n0, 0, (K + BK - 1) / BK, lds, acc);
+    if constexpr (Loader<1, BK>::kBuffer)
+        tile_mainloop_b<BM, BN, WM, WN, BK, Loader, Args>(args, Wt, ldw, M, N, K, m0, n0, 0, K / BK, lds, acc);
+    else
+        tile_mainloop<BM, BN, WM, WN, BK, Loader, Args>(args, Wt, ldw, M, N, K, m0, n0, 0, (K + BK - 1) / BK, lds, acc);
     tile_epilogue<BM, BN, WM, WN, BK, EPI_LDS>(lds, ep, m0, n0, M, N, acc);
 }
 
@@ -399,7 +643,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_streamk_kernel(Args args, const
         const int n0 = (tile % tiles_n) * BN;
         f32x16 acc[T::FM][T::FN];
         zero_acc(acc);
-        tile_mainloop<BM, BN, WM, WN, BK, Loader, Args>(args, Wt, ldw, M, N, K, m0, n0, kb, ke, lds, acc);
+        if constexpr (Loader<1, BK>::kBuffer)
+            tile_mainloop_b<BM, BN, WM, WN, BK, Loader, Args>(args, Wt, ldw, M, N, K, m0, n0, kb, ke, lds, acc);
+        else
+            tile_mainloop<BM, BN, WM, WN, BK, Loader, Args>(args, Wt, ldw, M, N, K, m0, n0, kb, ke, lds, acc);
         if (kb == 0 && ke == nk) {
             tile_epilogue<BM, BN, WM, WN, BK, EPI_LDS>(lds, ep, m0, n0, M, N, acc);
         } else {
@@ -570,8 +817,13 @@ void launch_shape(TileShape t, const Args& args, const float* Wt, int ldw, int M
     }
 }
 
-template <template <int, int> class Loader, class Args>
-int launch_tiles(const Args& args, const float* Wt, int ldw, int M, int N, int K, const Epilogue& ep, hipStream_t s) {
+int g_fast = 1;                      // RPG_TUNE_FAST_LOADER: buffer-load loaders + interleaved main loop where eligible
+
+// seg_align: 32 / 16 if every K segment of the A operand (gather widths, Cin) is a multiple of it and all offsets of
+// the buffer loaders fit in 32 bits, else 0 (general loaders).
+template <template <int, int> class Loader, template <int, int> class LoaderB, class Args>
+int launch_tiles(const Args& args, const float* Wt, int ldw, int M, int N, int K, const Epilogue& ep, hipStream_t s,
+                 int seg_align) {
     const TileShape t = pick_tile(M, N, K);
     const int bk = g_bk ? g_bk : ((t == TILE_128x128 && K >= 256) ? 32 : 16);
     // 16-byte epilogue accesses need 4-column groups: N % 4 == 0 and 16-byte aligned rows
@@ -580,11 +832,15 @@ int launch_tiles(const Args& args, const float* Wt, int ldw, int M, int N, int K
                         (ep.ldr % 4 == 0) && (!ep.scale || rpg::aligned16(ep.scale)) &&
                         (!ep.shift || rpg::aligned16(ep.shift));
     const bool epi = g_epi_lds && vec_ok;
+    const bool fast = g_fast && epi && seg_align > 0 && seg_align % bk == 0 && K % bk == 0 &&
+                      (long)N * ldw * 4 < (1L << 31);
     if (bk == 32) {
-        if (epi) launch_shape<32, true, Loader, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
+        if (fast) launch_shape<32, true, LoaderB, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
+        else if (epi) launch_shape<32, true, Loader, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
         else launch_shape<32, false, Loader, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
     } else {
-        if (epi) launch_shape<16, true, Loader, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
+        if (fast) launch_shape<16, true, LoaderB, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
+        else if (epi) launch_shape<16, true, Loader, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
         else launch_shape<16, false, Loader, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
     }
     return 0;
@@ -610,7 +866,11 @@ int launch_conv(const float* x, const float* w, const float* scale, const float*
     ConvArgs a{x, h, wd, cin, kh, kw, stride, pad, ho, wo};
     Epilogue ep{scale, shift, residual, y, cout, relu};
     const int slot = timing_begin(RPG_TIMER_CONV, s);
-    launch_tiles<ConvLoader, ConvArgs>(a, w, (int)K, (int)M, cout, (int)K, ep, s);
+    // buffer loaders: offsets are relative to the first image of a tile, whose <= 256 rows span at most
+    // 256 / (ho*wo) + 2 images
+    const long span = 256 / ((long)ho * wo) + 2;
+    const int seg = span * h * wd * cin * 4 >= (1L << 31) ? 0 : (cin % 32 == 0 ? 32 : (cin % 16 == 0 ? 16 : 0));
+    launch_tiles<ConvLoader, ConvLoaderB, ConvArgs>(a, w, (int)K, (int)M, cout, (int)K, ep, s, seg);
     timing_end(slot, 2.0 * (double)M * cout * (double)kh * kw * (alg_cin > 0 ? alg_cin : cin), s);
     RPG_CHECK_LAUNCH("conv2d_bn_act");
     return RPG_OK;
@@ -643,7 +903,13 @@ int launch_linear(const GatherSrc& src, const float* weight, const float* bias, 
         ep.ldr = gres->ld;
     }
     const int slot = timing_begin(RPG_TIMER_LINEAR, s);
-    launch_tiles<GatherLoader, GatherArgs>(a, weight, K, m, n_out, K, ep, s);
+    int seg = 32;
+    for (int i = 0; i < src.n; ++i) {
+        if (src.width[i] % 32) seg = src.width[i] % 16 ? 0 : (seg ? 16 : 0);
+        const long rows = src.idx[i] ? src.rows[i] : (long)m;          // a gathered source needs its row count
+        if (rows <= 0 || rows * src.ld[i] * 4 >= (1L << 31)) seg = 0;
+    }
+    launch_tiles<GatherLoader, GatherLoaderB, GatherArgs>(a, weight, K, m, n_out, K, ep, s, seg);
     timing_end(slot, 2.0 * (double)m * n_out * (double)K, s);
     RPG_CHECK_LAUNCH("linear_gather");
     return RPG_OK;
@@ -681,6 +947,7 @@ extern "C" int rpg_set_tuning(int key, int value) {
         case RPG_TUNE_STREAMK: g_streamk = value != 0; return RPG_OK;
         case RPG_TUNE_BF16_BK: if (value != 32 && value != 64) return RPG_ERR_BAD_ARG; rpg::bf16_set_bk(value); return RPG_OK;
         case RPG_TUNE_GNN_SPLIT: g_gnn_split = value != 0; return RPG_OK;
+        case RPG_TUNE_FAST_LOADER: g_fast = value != 0; return RPG_OK;
         case RPG_TUNE_WINOGRAD: if (value < 0 || value > 3) return RPG_ERR_BAD_ARG; rpg::wino_set(value); return RPG_OK;
         default: return RPG_ERR_BAD_ARG;
     }

@@ -35,6 +35,7 @@ struct GatherSrc {
     int ld[3];
     int width[3];
     int n;
+    long rows[3];          // rows of a[i] when idx[i] is given (0 = unknown: the 32-bit-offset fast path is not used)
 };
 
 int launch_conv(const float* x, const float* w, const float* scale, const float* shift, const float* residual,
