@@ -223,16 +223,17 @@ def main():
                 with open(tpath) as f:
                     tj = json.load(f)
                 traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/r1_pmc_traffic_wino43.json (rocprofv3 --pmc, corrected)"
-                pmc = {k: tj[k] for k in ("executed_mfma_gflop_per_launch", "mfma_busy_frac", "shader_clock_ghz") if k in tj}
+                pmc = {k: tj[k] for k in ("executed_mfma_gflop_per_launch", "mfma_busy_frac", "cu_busy_frac", "shader_clock_ghz") if k in tj}
             line["roofline"] = {
                 "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "wino43_conv_kernel (3x3/stride-1 conv + BN (+residual) + ReLU as 1-D Winograd F(4,3) on "
+                "kernel": "wino43_conv8_kernel (3x3/stride-1 conv + BN (+residual) + ReLU as 1-D Winograd F(4,3) on "
                           "v_mfma_f32_32x32x2_f32; 29 of the 36 ResNet34 convolutions)",
                 "launches": c["launches"], "avg_launch_ms": round(c["ms"] / c["launches"], 4),
                 "alg_gflop_per_launch": round(c["work"] / c["launches"] / 1e9, 3),
                 "note": "achieved = ALGORITHMIC (direct-convolution) FLOP / duration; F(4,3) executes ~0.5-0.57x of them "
-                        "on the matrix pipe, so the pipe itself is ~55 % busy (PMC SQ_VALU_MFMA_BUSY_CYCLES, see DESIGN.md)",
+                        "on the matrix pipe, so frac can exceed 1; the pipe's own occupancy is pmc.mfma_busy_frac "
+                        "(SQ_VALU_MFMA_BUSY_CYCLES, see DESIGN.md)",
                 "pmc": pmc,
                 "share_of_instrumented_step_time": round(c["ms"] / (1e3 * elapsed_ev), 4),
                 "measured_on": f"{args.steps} further steps of the same workload, one stream, per-launch HIP events: "

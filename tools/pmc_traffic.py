@@ -28,5 +28,24 @@ res = {"kernel": sub, "launches_sampled": nf, "FETCH_SIZE_avg": f, "WRITE_SIZE_a
                      "(MI355X_MICROARCH.md, HBM section); separate --pmc passes for the two counters",
        "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --steps 3 --warmup 1 "
                   "--cpu-baseline-seconds 0 --streams 1 --no-kernel-timing"}
+# optional third pass: matrix-pipe occupancy (pmc_mfma: SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_F32)
+import os
+mp = f"{root}/pmc_mfma/p_counter_collection.csv"
+if os.path.exists(mp):
+    busy, _ = mean_counter(mp, sub, "SQ_VALU_MFMA_BUSY_CYCLES")
+    gui, _ = mean_counter(mp, sub, "GRBM_GUI_ACTIVE")
+    cu, _ = mean_counter(mp, sub, "SQ_BUSY_CU_CYCLES")
+    insts, _ = mean_counter(mp, sub, "SQ_INSTS_VALU_MFMA_F32")
+    dur = []
+    for r in csv.DictReader(open(f"{root}/pmc_mfma/p_kernel_trace.csv")):
+        if sub in r["Kernel_Name"]:
+            dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
+    cycles = gui / 8.0                                   # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    res.update({"SQ_INSTS_VALU_MFMA_F32_avg": insts, "executed_mfma_gflop_per_launch": round(insts * 4096 / 1e9, 2),
+                "SQ_VALU_MFMA_BUSY_CYCLES_avg": busy, "GRBM_GUI_ACTIVE_avg_sum_over_8_xcd": gui,
+                "mfma_busy_frac": round(busy / (1024 * cycles), 4), "cu_busy_frac": round(cu / (256 * cycles), 4),
+                "shader_clock_ghz": round(cycles / (sum(dur) / len(dur)) / 1e9, 3),
+                "mfma_pass": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE "
+                             "SQ_INSTS_VALU_MFMA_F32 (same command); busy = BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8)"})
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
