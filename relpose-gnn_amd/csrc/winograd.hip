@@ -56,17 +56,55 @@ __device__ __forceinline__ float4 sub(const float4& x, const float4& y) {
 // cout) element of all 6 products in the same lane), then an LDS transpose to 16-byte row segments and the fused
 // BatchNorm / residual / ReLU / store, two of the four pixel columns at a time.  mw0 = first tile of the wave's 32,
 // nw0 = first output channel of its 32; slab = 64 x 36 floats of LDS private to the wave.
+// Nothing overlaps an epilogue when a CU holds one workgroup, so it is written for latency: the 16 row addresses of a
+// lane are computed once with ONE integer division (the rest is incremental), residual reads and output stores are raw
+// buffer accesses based at the wave's first image row (invalid rows / columns / channels carry an out-of-range offset:
+// reads return zero, stores are dropped), hence branch-free, and the 8 residual reads of a half are all in flight
+// before its transform starts instead of one dependent round trip per row.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void wino43_epilogue(const f32x16 (&acc)[P], float* slab, int lane, int mw0, int nw0, int M,
                                                 int Tw, int W, int Cout, const Epi& ep) {
     constexpr int EP = 32 + 4;                              // slab pitch: 32 channels + pad
+    constexpr unsigned OOB = 0x80000000u;
     const int c4 = lane & 7, pr = lane >> 3;                // 8 lanes cover a row's 32 channels; 8 rows per pass
     const int nb = nw0 + 4 * c4;
     const bool n_ok = nb < Cout;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
     if (n_ok && ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + nb);
     if (n_ok && ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + nb);
+
+    // this lane stores pixel column 4*tw + (pr & 1) [+ 2 in the second half] of tiles mw0 + (pr >> 1) + 4*it, it = 0..7
+    const int t_first = mw0 / Tw;                           // wave-uniform: first image row (n*H + ho) of the wave
+    const size_t row0 = (size_t)t_first * W * Cout;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ep.out + row0, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(ep.residual ? ep.residual + row0 : ep.out + row0), 0, 0x7fffffff, 0x00020000);
+    const int step_t = 4 / Tw, step_tw = 4 % Tw;            // wave-uniform
+    int mt = mw0 + (pr >> 1);
+    int trel = mt / Tw - t_first, tw = mt % Tw;
+    unsigned voff[2][8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int wo = 4 * tw + (pr & 1);
+        const bool ok = n_ok && mt < M;
+        const unsigned o = 4u * (unsigned)((trel * W + wo) * Cout + nb);
+        voff[0][it] = ok && wo < W ? o : OOB;
+        voff[1][it] = ok && wo + 2 < W ? o + 8u * (unsigned)Cout : OOB;
+        mt += 4;
+        trel += step_t;
+        tw += step_tw;
+        if (tw >= Tw) { tw -= Tw; ++trel; }
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+        float4 rs[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) rs[it] = f4zero();
+        if (ep.residual) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                rs[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, voff[half][it], 0, 0));
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const float m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e];
@@ -87,22 +125,11 @@ __device__ __forceinline__ void wino43_epilogue(const f32x16 (&acc)[P], float* s
         for (int it = 0; it < 8; ++it) {
             const int prow = pr + 8 * it;                               // 0..63 = (tile, pixel-in-half)
             const float4 v = *reinterpret_cast<const float4*>(&slab[prow * EP + 4 * c4]);
-            const int mt = mw0 + (prow >> 1);
-            if (mt < M && n_ok) {
-                const int tw = mt % Tw;
-                const int t = mt / Tw;                                  // = n*H + ho
-                const int wo = 4 * tw + 2 * half + (prow & 1);
-                if (wo < W) {
-                    const size_t o = ((size_t)t * W + wo) * Cout + nb;
-                    float4 rs = f4zero();
-                    if (ep.residual) rs = *reinterpret_cast<const float4*>(ep.residual + o);
-                    float4 y;
-                    y.x = v.x * sc.x + sh.x + rs.x; y.y = v.y * sc.y + sh.y + rs.y;
-                    y.z = v.z * sc.z + sh.z + rs.z; y.w = v.w * sc.w + sh.w + rs.w;
-                    if (ep.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
-                    *reinterpret_cast<float4*>(ep.out + o) = y;
-                }
-            }
+            float4 y;
+            y.x = v.x * sc.x + sh.x + rs[it].x; y.y = v.y * sc.y + sh.y + rs[it].y;
+            y.z = v.z * sc.z + sh.z + rs[it].z; y.w = v.w * sc.w + sh.w + rs[it].w;
+            if (ep.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, voff[half][it], 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -529,7 +556,9 @@ bool wino_pays(int n, int h, int w, int cin, int cout) {
     if (!g_wino || (cin & 3) || (cout & 3)) return false;
     const long tiles = (long)n * h * ((w + 3) / 4);
     const long blocks = ((tiles + BMT - 1) / BMT) * ((cout + BN - 1) / BN);
-    return blocks >= 128 && (long)h * w * cin * 4 * 67 < (1L << 31) && 6L * cout * 3 * cin * 4 < (1L << 31);
+    const int tw = (w + 3) / 4;
+    return blocks >= 128 && (long)h * w * cin * 4 * 67 < (1L << 31) && 6L * cout * 3 * cin * 4 < (1L << 31) &&
+           (32L / tw + 3) * w * cout * 4 < (1L << 31);
 }
 
 int launch_conv_wino(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
@@ -542,7 +571,9 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
     const long M = (long)n * h * tw;
     // 32-bit buffer offsets: a workgroup's 64 tiles span at most 65 images (+ 3 rows of scalar offset); U is
     // addressed from its base
-    if (M >= (1L << 31) || (long)h * w * cin * 4 * 67 >= (1L << 31) || 6L * cout * 3 * cin * 4 >= (1L << 31))
+    // the epilogue addresses the output rows of a wave's 32 tiles (<= 32/tw + 2 image rows) from its first row
+    if (M >= (1L << 31) || (long)h * w * cin * 4 * 67 >= (1L << 31) || 6L * cout * 3 * cin * 4 >= (1L << 31) ||
+        (32L / tw + 3) * w * cout * 4 >= (1L << 31))
         return RPG_ERR_BAD_ARG;
     static bool attr = false;
     if (!attr) {
