@@ -237,6 +237,71 @@ struct ConvLoaderB {
     }
 };
 
+// The 4-channel stem (Cin == 4: one 16-byte k-slot = all channels of ONE kernel tap): thread slot s walks taps
+// s, s + SLOTS, ...  Validity of (row, tap) is a K-invariant 64-bit mask per row (bit tap = pixel inside the image),
+// the tap's offset relative to the row's top-left pixel is per-thread and advances incrementally, so a load costs a
+// 64-bit shift, a test, an add and a select instead of the general loader's bounds arithmetic and conditional load.
+template <int R, int BK>
+struct ConvLoaderTap {
+    static constexpr bool kBuffer = true;
+    static constexpr int SLOTS = BK / 4, ROWS_PER_PASS = NTHREADS / SLOTS;
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned long long mask[R];       // bit t: tap t of this row reads a pixel inside the image
+    int rowoff[R];                    // byte offset of the row's (hi0, wi0) pixel relative to the tile's first image (may be < 0)
+    int W, KW, taps;
+    int tap, kh, kw, k0, kend;        // this thread's current tap; k0 wave-uniform
+
+    __device__ __forceinline__ void init(const ConvArgs& a, int m0, int M, int tid, int kbase, int kend_) {
+        W = a.W; KW = a.KW; taps = a.KH * a.KW; kend = kend_;
+        const int r0 = tid / SLOTS;
+        const int n_first = m0 / (a.Ho * a.Wo);
+        const int img = a.H * a.W * 4;
+        rs = make_rsrc(a.x + (size_t)n_first * img);
+        // (n, ho, wo) of the first row by division, of the others incrementally (rows are ROWS_PER_PASS pixels apart);
+        // the tap mask is the outer product of the valid kernel rows and the valid kernel columns
+        int m = m0 + r0;
+        int wo = m % a.Wo;
+        int t = m / a.Wo;
+        int ho = t % a.Ho;
+        int n = t / a.Ho - n_first;
+        const int dwo = ROWS_PER_PASS % a.Wo, dho = ROWS_PER_PASS / a.Wo;     // wave-uniform
+        const unsigned long long ones = (1ull << a.KW) - 1ull;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            mask[j] = 0ull; rowoff[j] = 0;
+            if (m < M) {
+                const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+                rowoff[j] = 4 * (n * img + (hi0 * a.W + wi0) * 4);
+                const int xlo = max(0, -wi0), xhi = min(a.KW, a.W - wi0);        // valid kernel columns [xlo, xhi)
+                const unsigned long long cm = xhi > xlo ? (ones >> (a.KW - (xhi - xlo))) << xlo : 0ull;
+                const int ylo = max(0, -hi0), yhi = min(a.KH, a.H - hi0);        // valid kernel rows [ylo, yhi)
+                unsigned long long mk = 0ull;
+                for (int y = ylo; y < yhi; ++y) mk |= cm << (y * a.KW);
+                mask[j] = mk;
+            }
+            m += ROWS_PER_PASS;
+            wo += dwo; ho += dho;
+            if (wo >= a.Wo) { wo -= a.Wo; ++ho; }
+            while (ho >= a.Ho) { ho -= a.Ho; ++n; }
+        }
+        k0 = kbase;
+        tap = kbase / 4 + tid % SLOTS;
+        kh = tap / KW;
+        kw = tap - kh * KW;
+    }
+    __device__ __forceinline__ float4 fetch_one(int j) const {
+        const bool ok = tap < taps && k0 < kend && ((mask[j] >> tap) & 1ull);
+        return buf_ld4(rs, ok ? (unsigned)(rowoff[j] + 16 * (kh * W + kw)) : OOB, 0u);
+    }
+    __device__ __forceinline__ void advance() {
+        k0 += BK;
+        tap += SLOTS;
+        kw += SLOTS;                  // KW >= 4 (host-checked): one wrap step for 4 slots, two for 8
+        if (kw >= KW) { kw -= KW; ++kh; }
+        if constexpr (SLOTS > 4) { if (kw >= KW) { kw -= KW; ++kh; } }
+    }
+};
+
 template <int R, int BK>
 struct GatherLoaderB {
     static constexpr bool kBuffer = true;
@@ -425,19 +490,30 @@ __device__ __forceinline__ void tile_mainloop_b(const Args& args, const float* _
     Loader<RA, BK> la;
     la.init(args, m0, M, tid, ks * BK, kend);
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(Wt);
-    unsigned woff[RW];
+    unsigned woff[RW], weff[RW];
 #pragma unroll
     for (int j = 0; j < RW; ++j) {
         const int n = n0 + srow + ROWS_PER_PASS * j;
         woff[j] = n < N ? 4u * (unsigned)(n * ldw + 4 * slot) : OOB;
     }
     int kw_ = ks * BK;                 // wave-uniform K position of the next W fetch
+    auto refresh_w = [&]() {           // K tail (K % BK != 0) and the steps past the end read zeros
+        asm volatile("");
+        const bool live = kw_ < kend && kw_ + 4 * slot < K;
+#pragma unroll
+        for (int j = 0; j < RW; ++j) weff[j] = live ? woff[j] : OOB;
+    };
+    refresh_w();
     float4 rr[NJ];                     // staging registers: A rows 0..RA-1, then W rows
     auto load_job = [&](int q) {
         if (q < RA) rr[q] = la.fetch_one(q);
-        else rr[q] = buf_ld4(rsw, kw_ < kend ? woff[q - RA] : OOB, 4u * (unsigned)kw_);
+        else rr[q] = buf_ld4(rsw, weff[q - RA], 4u * (unsigned)kw_);
     };
-    auto next_k = [&]() { la.advance(); kw_ += BK; };
+    auto next_k = [&]() {
+        la.advance();
+        kw_ += BK;
+        if (kw_ + BK > K || kw_ >= kend) refresh_w();
+    };
     const int st_off = srow * LDS_LD + 4 * slot;
     auto write_job = [&](int q, int img) {
         const int r = q < RA ? ROWS_PER_PASS * q : BM + ROWS_PER_PASS * (q - RA);
@@ -599,7 +675,9 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[FM][FN]) {
 
 // Data-parallel kernel: one workgroup per output tile, whole K range.
 template <int BM, int BN, int WM, int WN, int BK, bool EPI_LDS, template <int, int> class Loader, class Args>
-__global__ __launch_bounds__(NTHREADS) void gemm_tile_kernel(Args args, const float* __restrict__ Wt, int ldw,
+// the 256x64 / BK=16 tiles (Cout = 64: the stem) have short K loops; three workgroups per CU overlap their prologues
+// and epilogues
+__global__ __launch_bounds__(NTHREADS, (BM == 256 && BK == 16) ? 3 : 1) void gemm_tile_kernel(Args args, const float* __restrict__ Wt, int ldw,
                                                              int M, int N, int K, Epilogue ep, int tiles_n) {
     using T = Tile<BM, BN, WM, WN, BK>;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * STAGE floats
@@ -613,7 +691,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tile_kernel(Args args, const fl
     f32x16 acc[T::FM][T::FN];
     zero_acc(acc);
     if constexpr (Loader<1, BK>::kBuffer)
-        tile_mainloop_b<BM, BN, WM, WN, BK, Loader, Args>(args, Wt, ldw, M, N, K, m0, n0, 0, K / BK, lds, acc);
+        tile_mainloop_b<BM, BN, WM, WN, BK, Loader, Args>(args, Wt, ldw, M, N, K, m0, n0, 0, (K + BK - 1) / BK, lds, acc);
     else
         tile_mainloop<BM, BN, WM, WN, BK, Loader, Args>(args, Wt, ldw, M, N, K, m0, n0, 0, (K + BK - 1) / BK, lds, acc);
     tile_epilogue<BM, BN, WM, WN, BK, EPI_LDS>(lds, ep, m0, n0, M, N, acc);
@@ -821,7 +899,8 @@ int g_fast = 1;                      // RPG_TUNE_FAST_LOADER: buffer-load loader
 
 // seg_align: 32 / 16 if every K segment of the A operand (gather widths, Cin) is a multiple of it and all offsets of
 // the buffer loaders fit in 32 bits, else 0 (general loaders).
-template <template <int, int> class Loader, template <int, int> class LoaderB, class Args>
+// seg_align == -1: the A operand is a 4-channel convolution input (ConvLoaderTap via LoaderT; any K).
+template <template <int, int> class Loader, template <int, int> class LoaderB, template <int, int> class LoaderT, class Args>
 int launch_tiles(const Args& args, const float* Wt, int ldw, int M, int N, int K, const Epilogue& ep, hipStream_t s,
                  int seg_align) {
     const TileShape t = pick_tile(M, N, K);
@@ -834,6 +913,11 @@ int launch_tiles(const Args& args, const float* Wt, int ldw, int M, int N, int K
     const bool epi = g_epi_lds && vec_ok;
     const bool fast = g_fast && epi && seg_align > 0 && seg_align % bk == 0 && K % bk == 0 &&
                       (long)N * ldw * 4 < (1L << 31);
+    if (g_fast && epi && seg_align == -1 && (long)N * ldw * 4 < (1L << 31)) {
+        if (bk == 32) launch_shape<32, true, LoaderT, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
+        else launch_shape<16, true, LoaderT, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
+        return 0;
+    }
     if (bk == 32) {
         if (fast) launch_shape<32, true, LoaderB, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
         else if (epi) launch_shape<32, true, Loader, Args>(t, args, Wt, ldw, M, N, K, ep, vec_ok, s);
@@ -869,8 +953,9 @@ int launch_conv(const float* x, const float* w, const float* scale, const float*
     // buffer loaders: offsets are relative to the first image of a tile, whose <= 256 rows span at most
     // 256 / (ho*wo) + 2 images
     const long span = 256 / ((long)ho * wo) + 2;
-    const int seg = span * h * wd * cin * 4 >= (1L << 31) ? 0 : (cin % 32 == 0 ? 32 : (cin % 16 == 0 ? 16 : 0));
-    launch_tiles<ConvLoader, ConvLoaderB, ConvArgs>(a, w, (int)K, (int)M, cout, (int)K, ep, s, seg);
+    int seg = span * h * wd * cin * 4 >= (1L << 31) ? 0 : (cin % 32 == 0 ? 32 : (cin % 16 == 0 ? 16 : 0));
+    if (cin == 4 && kh * kw <= 64 && kw >= 4 && span * h * wd * cin * 4 < (1L << 31)) seg = -1;      // the stem: one tap per k-slot
+    launch_tiles<ConvLoader, ConvLoaderB, ConvLoaderTap, ConvArgs>(a, w, (int)K, (int)M, cout, (int)K, ep, s, seg);
     timing_end(slot, 2.0 * (double)M * cout * (double)kh * kw * (alg_cin > 0 ? alg_cin : cin), s);
     RPG_CHECK_LAUNCH("conv2d_bn_act");
     return RPG_OK;
@@ -909,7 +994,7 @@ int launch_linear(const GatherSrc& src, const float* weight, const float* bias, 
         const long rows = src.idx[i] ? src.rows[i] : (long)m;          // a gathered source needs its row count
         if (rows <= 0 || rows * src.ld[i] * 4 >= (1L << 31)) seg = 0;
     }
-    launch_tiles<GatherLoader, GatherLoaderB, GatherArgs>(a, weight, K, m, n_out, K, ep, s, seg);
+    launch_tiles<GatherLoader, GatherLoaderB, GatherLoaderB, GatherArgs>(a, weight, K, m, n_out, K, ep, s, seg);
     timing_end(slot, 2.0 * (double)m * n_out * (double)K, s);
     RPG_CHECK_LAUNCH("linear_gather");
     return RPG_OK;
