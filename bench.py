@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU the batch is spread over in the timed region")
     ap.add_argument("--bf16-bk", type=int, default=0, help="K step of the bf16 conv kernel (32|64; 0 = library default)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="rpg_set_tuning(KEY, VALUE) before the run, for A/B experiments (e.g. --tune 8=0: no Winograd split-K tail)")
     ap.add_argument("--encoder-dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 = the headline configuration (configs[1]); bf16 = configs[2] (bf16 activations + MFMA conv)")
     return ap.parse_args()
@@ -139,6 +141,9 @@ def main():
     model.encoder_dtype = args.encoder_dtype
     if args.bf16_bk:
         ops.set_tuning(ops.TUNE_BF16_BK, args.bf16_bk)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        ops.set_tuning(int(k), int(v))
 
     B = args.graphs
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)

@@ -935,6 +935,8 @@ int launch_tiles(const Args& args, const float* Wt, int ldw, int M, int N, int K
 namespace rpg {
 
 bool gnn_split_enabled() { return g_gnn_split != 0; }
+float* stream_scratch(hipStream_t s, size_t bytes) { return get_scratch(s, bytes); }
+int num_cus() { return cu_count(); }
 
 int launch_conv(const float* x, const float* w, const float* scale, const float* shift, const float* residual,
                 float* y, int n, int h, int wd, int cin, int cout, int kh, int kw, int stride, int pad, int relu,
@@ -1033,6 +1035,7 @@ extern "C" int rpg_set_tuning(int key, int value) {
         case RPG_TUNE_BF16_BK: if (value != 32 && value != 64) return RPG_ERR_BAD_ARG; rpg::bf16_set_bk(value); return RPG_OK;
         case RPG_TUNE_GNN_SPLIT: g_gnn_split = value != 0; return RPG_OK;
         case RPG_TUNE_FAST_LOADER: g_fast = value != 0; return RPG_OK;
+        case RPG_TUNE_WINO_SPLIT: rpg::wino_split_set(value != 0); return RPG_OK;
         case RPG_TUNE_WINOGRAD: if (value < 0 || value > 3) return RPG_ERR_BAD_ARG; rpg::wino_set(value); return RPG_OK;
         default: return RPG_ERR_BAD_ARG;
     }

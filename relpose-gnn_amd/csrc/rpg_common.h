@@ -43,11 +43,15 @@ int launch_conv(const float* x, const float* w, const float* scale, const float*
                 hipStream_t s, int alg_cin = 0 /* channels counted as algorithmic work; 0 = cin */);
 int launch_conv_wino(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
                      float* y, int n, int h, int w, int cin, int cout, int relu, hipStream_t s);
+// per-stream scratch for split-K partial tiles (grown on demand; consumers run in stream order) and the CU count
+float* stream_scratch(hipStream_t s, size_t bytes);
+int num_cus();
 bool wino_enabled();
 // true if the composite forward should route this 3x3/stride-1 convolution to launch_conv_wino (enabled, shape
 // addressable, and large enough that the un-split K loop is not latency-bound)
 bool wino_pays(int n, int h, int w, int cin, int cout);
 void wino_set(int on);
+void wino_split_set(int on);
 // Gathered residual rows added in the epilogue: out[m] += res1[idx1[m]] (+ res2[idx2[m]]), row pitch ld.
 struct GatherRes {
     const float* res1;

@@ -135,6 +135,41 @@ __device__ __forceinline__ void wino43_epilogue(const f32x16 (&acc)[P], float* s
     }
 }
 
+// Split-K variant: the wave's raw output-transformed tile goes to dst[512 px][64 ch] of its workgroup's slab
+// (px = 4 * tile-in-workgroup + pixel column); no masking, the fix-up kernel knows what is valid.
+__device__ __forceinline__ void wino43_epilogue_partial(const f32x16 (&acc)[P], float* slab, int lane, int mw, int nw,
+                                                        float* __restrict__ dst) {
+    constexpr int EP = 32 + 4;
+    const int c4 = lane & 7, pr = lane >> 3;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e];
+            float ya, yb;
+            if (half == 0) {
+                ya = acc[0][e] + m1 + m2 + m3 + m4;
+                yb = (m1 - m2) + 2.f * (m3 - m4);
+            } else {
+                ya = (m1 + m2) + 4.f * (m3 + m4);
+                yb = (m1 - m2) + 8.f * (m3 - m4) + acc[5][e];
+            }
+            const int trow = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            slab[(2 * trow) * EP + (lane & 31)] = ya;
+            slab[(2 * trow + 1) * EP + (lane & 31)] = yb;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int prow = pr + 8 * it;                               // (tile, pixel-in-half)
+            const float4 v = *reinterpret_cast<const float4*>(&slab[prow * EP + 4 * c4]);
+            const int px = 4 * (mw + (prow >> 1)) + 2 * half + (prow & 1);
+            *reinterpret_cast<float4*>(dst + px * BN + nw + 4 * c4) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // x [n][H][W][Cin] -> y [n][H][W][Cout];  U [6][Cout][3][Cin];  M = n*H*Tw tiles, Tw = ceil(W/4)
 __global__ __launch_bounds__(NT, 2) void wino43_conv_kernel(const float* __restrict__ x, const float* __restrict__ U,
                                                          int H, int W, int Cin, int Cout, int Tw, int M, Epi ep,
@@ -350,14 +385,29 @@ RPG_F4_OP(add4, pk_add)
 RPG_F4_OP(sub4, pk_sub)
 #undef RPG_F4_OP
 
+// SPLIT: the tiles [tile_base, ..) that do not fill a whole round of CUs are cut along K into `parts` workgroups each,
+// which store their raw partial output tile (after the output transform: it is linear) as [512 px][64 ch] in slab
+// (tile - tile_base) * parts + part of `partial`; wino43_fixup_kernel adds the parts in k order and applies the epilogue.
+struct Split { int tile_base, parts; float* partial; };
+
+template <bool SPLIT>
 __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restrict__ x, const float* __restrict__ U, int H,
-                                                          int W, int Cin, int Cout, int Tw, int M, Epi ep, int tiles_n) {
+                                                          int W, int Cin, int Cout, int Tw, int M, Epi ep, int tiles_n,
+                                                          Split sp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int K = 3 * Cin;
-
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r8 = nwg & 7;
-    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+    const int kpr = (Cin + BK - 1) / BK;               // K steps per kernel row
+    int tile, kb = 0, nk = 3 * kpr;                    // this workgroup's tile and K-step range [kb, nk)
+    if constexpr (SPLIT) {
+        const int tt = blockIdx.x / sp.parts, part = blockIdx.x - tt * sp.parts;
+        tile = sp.tile_base + tt;
+        kb = part * nk / sp.parts;
+        nk = (part + 1) * nk / sp.parts;
+    } else {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r8 = nwg & 7;
+        tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+    }
     const int m0 = (tile / tiles_n) * BMT8;
     const int n0 = (tile % tiles_n) * BN;
 
@@ -395,8 +445,7 @@ __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restri
     const unsigned ustride_b = (unsigned)Cout * K * 4u;
     const unsigned vb = n0 + brow < Cout ? 4u * (unsigned)((n0 + brow) * K + 4 * slot) + 3u * bhalf * ustride_b : OOB;
     unsigned vb_eff;
-    const int nk = 3 * ((Cin + BK - 1) / BK);
-    int f_kt = 0, f_kh = 0, f_c0 = 0;     // the K step the next fetches load (wave-uniform)
+    int f_kt = kb, f_kh = kb / kpr, f_c0 = (kb % kpr) * BK;     // the K step the next fetches load (wave-uniform)
     auto refresh = [&]() {                // effective offsets of K step f_kt: row border, channel tail, past the end
         asm volatile("" ::: "memory");    // keeps this a (rarely taken) branch: if-converted it is 11 VALU per K step
         const bool cv = f_kt < nk && f_c0 + 4 * slot < Cin;
@@ -512,14 +561,46 @@ __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restri
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) frag_one(0, 0, i, 0);
-    int kt = 0;
+    int kt = kb;
     for (; kt + 1 < nk; kt += 2) {
         kstep(0, IMG8_FLOATS);
         kstep(IMG8_FLOATS, 0);
     }
     if (kt < nk) kstep(0, IMG8_FLOATS);
     __syncthreads();                     // LDS becomes the epilogue slabs
-    wino43_epilogue(acc, lds + wave * (64 * 36), lane, m0 + wm * 32, n0 + wn * 32, M, Tw, W, Cout, ep);
+    if constexpr (SPLIT)
+        wino43_epilogue_partial(acc, lds + wave * (64 * 36), lane, wm * 32, wn * 32,
+                                sp.partial + (size_t)blockIdx.x * (BMT8 * 4 * BN));
+    else
+        wino43_epilogue(acc, lds + wave * (64 * 36), lane, m0 + wm * 32, n0 + wn * 32, M, Tw, W, Cout, ep);
+}
+
+// Sums the `parts` partial slabs of tail tile blockIdx.x / 32 in k order and applies BatchNorm / residual / ReLU.
+__global__ __launch_bounds__(256) void wino43_fixup_kernel(const float* __restrict__ partial, Epi ep, int M, int Tw, int W,
+                                                           int Cout, int tiles_n, Split sp) {
+    const int tt = blockIdx.x >> 5, idx = (blockIdx.x & 31) * 256 + threadIdx.x;      // 512 px x 16 channel quads
+    const int p = idx >> 4, c4 = idx & 15;
+    const float* src = partial + (size_t)tt * sp.parts * (BMT8 * 4 * BN) + p * BN + 4 * c4;
+    float4 s = *reinterpret_cast<const float4*>(src);
+    for (int i = 1; i < sp.parts; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)i * (BMT8 * 4 * BN));
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int tile = sp.tile_base + tt;
+    const int m = (tile / tiles_n) * BMT8 + (p >> 2), nb = (tile % tiles_n) * BN + 4 * c4;
+    if (m >= M || nb >= Cout) return;
+    const int t = m / Tw, wo = 4 * (m - t * Tw) + (p & 3);
+    if (wo >= W) return;
+    const size_t o = ((size_t)t * W + wo) * Cout + nb;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero(), rs = f4zero();
+    if (ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + nb);
+    if (ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + nb);
+    if (ep.residual) rs = *reinterpret_cast<const float4*>(ep.residual + o);
+    float4 y;
+    y.x = s.x * sc.x + sh.x + rs.x; y.y = s.y * sc.y + sh.y + rs.y;
+    y.z = s.z * sc.z + sh.z + rs.z; y.w = s.w * sc.w + sh.w + rs.w;
+    if (ep.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+    *reinterpret_cast<float4*>(ep.out + o) = y;
 }
 
 // U[xi][co][kh][c] = sum_j G[xi][j] * w[co][kh][j][c], evaluated in double and rounded once.
@@ -540,6 +621,7 @@ __global__ __launch_bounds__(NT) void wino43_weights_kernel(const float* __restr
     for (int xi = 0; xi < 6; ++xi) U[xi * plane + i] = (float)u[xi];
 }
 
+int g_wino_split = 1;                    // RPG_TUNE_WINO_SPLIT: split-K tail of the 8-wave kernel
 int g_wino = 1;                          // RPG_TUNE_WINOGRAD: 0 off | 1 auto | 2 always the 4-wave kernel | 3 always the 8-wave kernel
 
 }  // namespace
@@ -548,6 +630,7 @@ namespace rpg {
 
 bool wino_enabled() { return g_wino != 0; }
 void wino_set(int on) { g_wino = on; }
+void wino_split_set(int on) { g_wino_split = on; }
 
 // Winograd needs (a) 32-bit buffer offsets (checked again by the launcher) and (b) enough 64-tile x 64-channel units
 // of work to occupy the chip: its K loop is not split, so a small grid is latency-bound (measured crossover vs the
@@ -587,15 +670,40 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
     const long tm8 = (M + BMT8 - 1) / BMT8;
     const bool fits8 = (long)h * w * cin * 4 * 131 < (1L << 31);     // a workgroup's 128 tiles span at most 129 images
     if (fits8 && (g_wino == 3 || (g_wino == 1 && tm8 * tn >= 64))) {
-        // large problems (or RPG_TUNE_WINOGRAD = 3): 8 waves on 128 tiles, double-buffered
+        // large problems (or RPG_TUNE_WINOGRAD = 3): 8 waves on 128 tiles, double-buffered, one workgroup per CU.
+        // The tiles beyond the last full round of CUs would cost a whole extra round (784 tiles on 256 CUs: a 4th
+        // round for 2 % of the work): they are cut along K into floor(CUs / tail) parts (>= 4 K steps each) whose partial
+        // tiles a small fix-up kernel adds in k order.
         static bool attr8 = false;
         if (!attr8) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino43_conv8_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino43_conv8_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino43_conv8_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
             attr8 = true;
         }
-        hipLaunchKernelGGL(wino43_conv8_kernel, dim3((unsigned)(tm8 * tn)), dim3(NT8), LDS8_BYTES, s, x, u, h, w, cin, cout,
-                           tw, (int)M, ep, tn);
+        const long T = tm8 * tn;
+        const int S = num_cus(), nk = 3 * ((cin + BK - 1) / BK);
+        long t_main = T;
+        Split sp{0, 1, nullptr};
+        const long tail = T % S;
+        if (g_wino_split && tail > 0) {
+            int parts = (int)(S / tail);
+            if (parts > nk / 4) parts = nk / 4;
+            if (parts >= 2) {
+                sp.partial = stream_scratch(s, (size_t)tail * parts * (BMT8 * 4 * BN) * sizeof(float));
+                if (sp.partial) { sp.parts = parts; t_main = T - tail; sp.tile_base = (int)t_main; }
+            }
+        }
+        if (t_main > 0)
+            hipLaunchKernelGGL(wino43_conv8_kernel<false>, dim3((unsigned)t_main), dim3(NT8), LDS8_BYTES, s, x, u, h, w, cin,
+                               cout, tw, (int)M, ep, tn, sp);
+        if (t_main < T) {
+            const unsigned rem = (unsigned)(T - t_main);
+            hipLaunchKernelGGL(wino43_conv8_kernel<true>, dim3(rem * sp.parts), dim3(NT8), LDS8_BYTES, s, x, u, h, w, cin, cout,
+                               tw, (int)M, ep, tn, sp);
+            hipLaunchKernelGGL(wino43_fixup_kernel, dim3(rem * 32), dim3(256), 0, s, sp.partial, ep, (int)M, tw, w, cout, tn, sp);
+        }
     } else {
         const int tm = (int)((M + BMT - 1) / BMT);
         hipLaunchKernelGGL(wino43_conv_kernel, dim3(tm * tn), dim3(NT), LDS_BYTES, s, x, u, h, w, cin, cout, tw, (int)M, ep, tn);
