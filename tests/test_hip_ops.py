@@ -265,6 +265,56 @@ def test_tile_engine_variants(dev, bk, epi, tile, streamk):
         ops.set_tuning(ops.TUNE_STREAMK, 1)
 
 
+@pytest.mark.parametrize("bk", [16, 32])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
+@pytest.mark.parametrize("streamk", [0, 1])
+def test_tile_engine_buffer_loaders(dev, bk, tile, streamk):
+    """The buffer-load loaders + interleaved main loop (ConvLoaderB, ConvLoaderTap, GatherLoaderB; used whenever every K
+    segment is a multiple of the K step) in every tile variant: a strided padded 3x3 conv (Cin = 64), the 7x7/2
+    4-channel stem (one tap per k-slot, K = 196 with a K tail), a 1x1/2 conv, and a two-source Linear without
+    gather; each against torch and against the general loaders (RPG_TUNE_FAST_LOADER = 0)."""
+    from relpose_gnn_amd import ops
+    convs = [  # n, h, w, cin, cout, k, stride, pad, residual
+        (3, 13, 17, 64, 72, 3, 2, 1, True),
+        (2, 37, 29, 4, 64, 7, 2, 3, False),
+        (5, 9, 11, 32, 40, 1, 2, 0, False),
+    ]
+    try:
+        ops.set_tuning(ops.TUNE_BK, bk)
+        ops.set_tuning(ops.TUNE_TILE, tile)
+        ops.set_tuning(ops.TUNE_STREAMK, streamk)
+        for ci, (n, h, w, cin, cout, k, st, pad, res) in enumerate(convs):
+            x = _rand(n, cin, h, w, seed=40 + ci)
+            wt = _rand(cout, cin, k, k, seed=50 + ci, scale=(2.0 / (cin * k * k)) ** 0.5)
+            scale = torch.rand(cout, generator=torch.Generator().manual_seed(60 + ci)) + 0.5
+            shift = _rand(cout, seed=70 + ci, scale=0.1)
+            ref = F.conv2d(x, wt, None, stride=st, padding=pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+            r = _rand(*ref.shape, seed=80 + ci) if res else None
+            if res:
+                ref = ref + r
+            ref = F.relu(ref)
+            args = (x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev), scale.to(dev),
+                    shift.to(dev), None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev))
+            y = ops.conv2d_bn_act_nhwc(*args, stride=st, pad=pad, relu=True)
+            assert rel_err(y.cpu().permute(0, 3, 1, 2), ref) < TOL, (ci, "vs torch")
+            ops.set_tuning(ops.TUNE_FAST_LOADER, 0)
+            y0 = ops.conv2d_bn_act_nhwc(*args, stride=st, pad=pad, relu=True)
+            ops.set_tuning(ops.TUNE_FAST_LOADER, 1)
+            assert rel_err(y.cpu(), y0.cpu()) < TOL, (ci, "vs general loader")
+        m, widths, n_out = 333, (64, 96), 100              # K = 160: segments are multiples of 32
+        srcs = [(_rand(m, wd, seed=90 + i).to(dev), None) for i, wd in enumerate(widths)]
+        k = sum(widths)
+        wl, bias, res = _rand(n_out, k, seed=95, scale=k ** -0.5), _rand(n_out, seed=96), _rand(m, n_out, seed=97)
+        ref = F.relu(F.linear(torch.cat([a.cpu() for a, _ in srcs], 1), wl, bias) + res)
+        out = ops.linear_gather(srcs, wl.to(dev), bias.to(dev), m, res.to(dev), True)
+        assert rel_err(out.cpu(), ref) < TOL
+    finally:
+        ops.set_tuning(ops.TUNE_BK, 0)
+        ops.set_tuning(ops.TUNE_TILE, -1)
+        ops.set_tuning(ops.TUNE_STREAMK, 1)
+        ops.set_tuning(ops.TUNE_FAST_LOADER, 1)
+
+
 @pytest.mark.parametrize("sizes,k,d", [((8, 8, 8), 4, 2048), ((8, 9, 3, 1), 4, 64), ((40,), 7, 128)])
 def test_knn_graph(dev, sizes, k, d):
     """rpg_knn_graph_f32 vs the oracle's restatement of torch_cluster.knn_graph (ragged graphs, graphs smaller than k+1)."""
