@@ -187,7 +187,7 @@ int rpg_timing_enable(int enable);
 int rpg_timing_read(double* ms, long long* launches, double* work);
 
 /* Tuning knobs of the f32 MFMA tile engine (benchmarking aid; defaults are the tuned choice).
- *   RPG_TUNE_TILE      -1 automatic (default) | 0: 128x128 | 1: 256x64 | 2: 64x64 workgroup tile
+ *   RPG_TUNE_TILE      -1 automatic (default) | 0: 128x128 | 1: 256x64 | 2: 64x64 | 3: 128x64 workgroup tile
  *   RPG_TUNE_BK        K-step: 0 automatic (default: 32 for the 128x128 tile, else 16) | 16 | 32
  *   RPG_TUNE_EPILOGUE  1: LDS-transposed 16-byte epilogue (default) | 0: direct 4-byte epilogue
  *   RPG_TUNE_STREAMK   1: stream-K pass for the tiles that do not fill a round of resident workgroups

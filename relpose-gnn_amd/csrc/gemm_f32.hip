@@ -788,10 +788,11 @@ __global__ __launch_bounds__(NTHREADS) void streamk_fixup_kernel(const float* __
     }
 }
 
-enum TileShape { TILE_128x128 = 0, TILE_256x64 = 1, TILE_64x64 = 2 };
+enum TileShape { TILE_128x128 = 0, TILE_256x64 = 1, TILE_64x64 = 2, TILE_128x64 = 3 };
 
 // Tuning knobs (rpg_set_tuning): -1 = automatic.
 int g_force_tile = -1;
+int g_tile_128x64 = 1;                // prefer 128x64 over 128x128 tiles for problems smaller than 1.5 big tiles per CU
 int g_bk = 0;                        // 0 = automatic: 32 for the 128x128 tile (2 workgroups/CU), else 16
 int g_epi_lds = 1;
 int g_streamk = 1;
@@ -827,12 +828,14 @@ int cu_count() {
 }
 
 inline TileShape pick_tile(int M, int N, int K) {
-    if (g_force_tile >= 0 && g_force_tile <= 2) return (TileShape)g_force_tile;
+    if (g_force_tile >= 0 && g_force_tile <= 3) return (TileShape)g_force_tile;
     if (N <= 64) return (M >= 256 * 256) ? TILE_256x64 : TILE_64x64;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (t128 >= 384) return TILE_128x128;                 // >= 1.5 big tiles per CU
     // fewer big tiles than CUs can balance: fine with stream-K when K is long enough to split, else go small
-    if (g_streamk && K >= 32 * SK_MIN_NK && (long)M * N >= 128L * 128 * 8) return TILE_128x128;
+    // (128x64 halves the tile so that twice as many workgroups share the work before stream-K has to split K: measured
+    // on the GNN Linears, M = 1792: N = 768 85 -> 68 us, N = 2048 142 -> 136 us; M = 256, N = 2048 63 -> 57 us)
+    if (g_streamk && K >= 32 * SK_MIN_NK && (long)M * N >= 128L * 128 * 8) return g_tile_128x64 ? TILE_128x64 : TILE_128x128;
     return TILE_64x64;
 }
 
@@ -891,6 +894,7 @@ void launch_shape(TileShape t, const Args& args, const float* Wt, int ldw, int M
     switch (t) {
         case TILE_128x128: launch_one<128, 128, 2, 2, BK, EPI, Loader, Args>(args, Wt, ldw, M, N, K, ep, vec_ok, s); break;
         case TILE_256x64: launch_one<256, 64, 4, 1, BK, EPI, Loader, Args>(args, Wt, ldw, M, N, K, ep, vec_ok, s); break;
+        case TILE_128x64: launch_one<128, 64, 2, 2, BK, EPI, Loader, Args>(args, Wt, ldw, M, N, K, ep, vec_ok, s); break;
         default: launch_one<64, 64, 2, 2, BK, EPI, Loader, Args>(args, Wt, ldw, M, N, K, ep, vec_ok, s); break;
     }
 }
@@ -904,7 +908,7 @@ template <template <int, int> class Loader, template <int, int> class LoaderB, t
 int launch_tiles(const Args& args, const float* Wt, int ldw, int M, int N, int K, const Epilogue& ep, hipStream_t s,
                  int seg_align) {
     const TileShape t = pick_tile(M, N, K);
-    const int bk = g_bk ? g_bk : ((t == TILE_128x128 && K >= 256) ? 32 : 16);
+    const int bk = g_bk ? g_bk : (((t == TILE_128x128 || t == TILE_128x64) && K >= 256) ? 32 : 16);
     // 16-byte epilogue accesses need 4-column groups: N % 4 == 0 and 16-byte aligned rows
     const bool vec_ok = (N % 4 == 0) && (ep.ldc % 4 == 0) && rpg::aligned16(ep.out) &&
                         (!ep.residual || rpg::aligned16(ep.residual)) && (!ep.residual2 || rpg::aligned16(ep.residual2)) &&

@@ -223,7 +223,7 @@ def test_bad_arguments_raise(dev):
 
 @pytest.mark.parametrize("bk", [16, 32])
 @pytest.mark.parametrize("epi", [0, 1])
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3])
 @pytest.mark.parametrize("streamk", [0, 1])
 def test_tile_engine_variants(dev, bk, epi, tile, streamk):
     """Every (K-step, epilogue, workgroup-tile) variant of the MFMA tile engine on a conv with ragged M, K tail,
@@ -266,7 +266,7 @@ def test_tile_engine_variants(dev, bk, epi, tile, streamk):
 
 
 @pytest.mark.parametrize("bk", [16, 32])
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3])
 @pytest.mark.parametrize("streamk", [0, 1])
 def test_tile_engine_buffer_loaders(dev, bk, tile, streamk):
     """The buffer-load loaders + interleaved main loop (ConvLoaderB, ConvLoaderTap, GatherLoaderB; used whenever every K
