@@ -240,6 +240,11 @@ def main():
                         "on the matrix pipe, so frac can exceed 1; the pipe's own occupancy is pmc.mfma_busy_frac "
                         "(SQ_VALU_MFMA_BUSY_CYCLES, see DESIGN.md)",
                 "pmc": pmc,
+                "executed": (None if "executed_mfma_gflop_per_launch" not in pmc else {
+                    "tflops": round(pmc["executed_mfma_gflop_per_launch"] / (c["ms"] / c["launches"]), 2),
+                    "frac_of_peak": round(pmc["executed_mfma_gflop_per_launch"] / (c["ms"] / c["launches"]) / F32_MATRIX_PEAK_TFLOPS, 4),
+                    "what": "FLOP the matrix pipe really executes per launch (SQ_INSTS_VALU_MFMA_F32 x 4096, committed PMC "
+                            "profile) / this run's average launch duration"}),
                 "share_of_instrumented_step_time": round(c["ms"] / (1e3 * elapsed_ev), 4),
                 "measured_on": f"{args.steps} further steps of the same workload, one stream, per-launch HIP events: "
                                f"{round(1e3 * elapsed_ev / args.steps, 3)} ms/step, vs "
