@@ -199,6 +199,7 @@ int rpg_timing_read(double* ms, long long* launches, double* work);
 #define RPG_TUNE_GNN_SPLIT 5      /* 1: per-node precompute of the split concatenated-input Linears (default, needs
                                      the 26-tensor table) | 0: reference formulation (gathered 3-source GEMMs) */
 #define RPG_TUNE_BF16_BK 6        /* K step of the bf16 convolution kernel: 32 (default) | 64 */
+#define RPG_TUNE_BF16_FAST 9      /* 1: interleaved buffer-load bf16 conv kernel where Cin % 64 == 0 (default) | 0: general kernel */
 #define RPG_TUNE_WINO_SPLIT 8     /* 1: split-K tail + fix-up for the 8-wave Winograd kernel (default) | 0: whole tiles only */
 #define RPG_TUNE_FAST_LOADER 7    /* 1: buffer-load loaders + interleaved main loop where eligible (default) | 0: general loaders */
 #define RPG_TUNE_WINOGRAD 4       /* 0: always the direct kernel | 1: use u_wino43 where given, kernel by size (default) |

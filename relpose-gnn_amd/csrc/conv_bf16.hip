@@ -41,6 +41,55 @@ __device__ __forceinline__ uint4 ld16_or_zero(const __bf16* p, bool ok) {
     return v;
 }
 
+// Epilogue shared by both kernels: each wave transposes its accumulators through a private fp32 LDS slab; each lane
+// finishes 4 consecutive channels of a row (BatchNorm scale/shift, bf16 residual, ReLU, bf16 or fp32 store).
+template <int FM, int FN, int SLAB_BUDGET_BYTES>
+__device__ __forceinline__ void bf16_tile_epilogue(f32x16 (&acc)[FM][FN], unsigned char* lds_raw, const EpiB& ep, int m0,
+                                                   int n0, int M, int N, int wm, int wn, int lane, int wave) {
+    constexpr int EW = FN * 32, EPITCH = EW + 4, C4 = EW / 4, RPI = 64 / C4, NIT = 32 / RPI;
+    static_assert(4 * 32 * EPITCH * 4 <= SLAB_BUDGET_BYTES, "epilogue slab does not fit the staging LDS");
+    float* slab = reinterpret_cast<float*>(lds_raw) + wave * (32 * EPITCH);
+    const int c4 = lane % C4, r_in = lane / C4;
+    const int nb = n0 + wn * EW + 4 * c4;
+    const bool n_ok = nb < N;                 // N % 4 == 0
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n_ok && ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + nb);
+    if (n_ok && ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + nb);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                slab[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * EPITCH + j * 32 + (lane & 31)] = acc[i][j][e];
+        __builtin_amdgcn_wave_barrier();
+        const int mb = m0 + (wm * FM + i) * 32;
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int row = r_in + RPI * t;
+            const int m = mb + row;
+            const float4 v = *reinterpret_cast<const float4*>(&slab[row * EPITCH + 4 * c4]);
+            if (n_ok && m < M) {
+                const size_t o = (size_t)m * ep.ldc + nb;
+                float4 y;
+                y.x = v.x * sc.x + sh.x; y.y = v.y * sc.y + sh.y; y.z = v.z * sc.z + sh.z; y.w = v.w * sc.w + sh.w;
+                if (ep.residual) {
+                    const bf16x4 rs = *reinterpret_cast<const bf16x4*>(ep.residual + o);
+                    y.x += (float)rs[0]; y.y += (float)rs[1]; y.z += (float)rs[2]; y.w += (float)rs[3];
+                }
+                if (ep.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+                if (ep.out_f32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(ep.out) + o) = y;
+                } else {
+                    const bf16x4 ob = {(__bf16)y.x, (__bf16)y.y, (__bf16)y.z, (__bf16)y.w};
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(ep.out) + o) = ob;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int BK>
 __global__ __launch_bounds__(NT) void conv_bf16_kernel(ConvArgsB a, const __bf16* __restrict__ Wt, int M, int N, int K,
                                                        EpiB ep, int tiles_n) {
@@ -167,57 +216,198 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(ConvArgsB a, const __bf16
         __syncthreads();
     }
 
-    // ---- epilogue: transpose through a per-wave fp32 LDS slab; each lane finishes 4 consecutive channels of a row
-    constexpr int EW = FN * 32, EPITCH = EW + 4, C4 = EW / 4, RPI = 64 / C4, NIT = 32 / RPI;
-    static_assert(4 * 32 * EPITCH * 4 <= 2 * STAGE * 2, "epilogue slab does not fit the staging LDS");
-    float* slab = reinterpret_cast<float*>(lds_raw) + wave * (32 * EPITCH);
-    const int c4 = lane % C4, r_in = lane / C4;
-    const int nb = n0 + wn * EW + 4 * c4;
-    const bool n_ok = nb < N;                 // N % 4 == 0
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n_ok && ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + nb);
-    if (n_ok && ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + nb);
+    bf16_tile_epilogue<FM, FN, 2 * STAGE * 2>(acc, lds_raw, ep, m0, n0, M, N, wm, wn, lane, wave);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The kernel for Cin % 64 == 0 (every convolution but the stem), built by the rules measured for the f32 engine
+// (gemm_f32.hip, tile_mainloop_b): nothing but MFMAs issues in clumps.  K step 64 elements = 128-byte LDS rows of
+// eight 16-byte chunks, unpadded, chunk c of row r stored at c ^ ((r >> 1) & 7) (conflict-free ds_read_b128 lane
+// groups, contiguous ds_write_b128 rows); two LDS images; raw buffer loads whose lane-dependent offsets are
+// K-invariant (rebuilt in a rarely taken branch when the kernel tap changes; out-of-image taps and ragged rows carry
+// an out-of-range offset = hardware zero fill) with the K position in the scalar offset; the stage writes of step
+// t+1, the loads of step t+2 and the operand reads of the next MFMA group are spread one or two at a time behind the
+// 4 x FM*FN MFMAs of step t (v_mfma_f32_32x32x16_bf16: 32 cycles each, LDS / VMEM instructions hide beside it); one
+// barrier per step, placed before the last MFMA group, which already reads the next image.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NT) void conv_bf16_fast_kernel(ConvArgsB a, const __bf16* __restrict__ Wt, int M, int N, int K,
+                                                            EpiB ep, int tiles_n) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int BK = 64, LD = BK, SLOTS = BK / 8, ROWS_PER_PASS = NT / SLOTS;      // 32 rows per staging pass
+    constexpr int FM = BM / WM / 32, FN = BN / WN / 32;
+    constexpr int RA = BM / ROWS_PER_PASS, RW = BN / ROWS_PER_PASS, NJ = RA + RW;
+    constexpr int KB = BK / 16, G = FM * FN, NR = FM + FN;
+    constexpr int STAGE = (BM + BN) * LD;                 // elements per LDS image
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int slot = tid % SLOTS, srow = tid / SLOTS;
+
+    // ---- A rows: element offset of the row's image relative to the tile's first image, top-left input pixel
+    const int n_first = m0 / (a.Ho * a.Wo);
+    const int img = a.H * a.W * a.Cin;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x) + (size_t)n_first * img, 0,
+                                                                          0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wt), 0, 0x7fffffff, 0x00020000);
+    int base[RA], hi0[RA], wi0[RA];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
+    for (int j = 0; j < RA; ++j) {
+        const int m = m0 + srow + ROWS_PER_PASS * j;
+        base[j] = -1; hi0[j] = 0; wi0[j] = 0;
+        if (m < M) {
+            const int wo = m % a.Wo;
+            const int t = m / a.Wo;
+            base[j] = (t / a.Ho - n_first) * img;
+            hi0[j] = (t % a.Ho) * a.stride - a.pad;
+            wi0[j] = wo * a.stride - a.pad;
+        }
+    }
+    unsigned voff[RA], woff[RW], weff[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+        const int n = n0 + srow + ROWS_PER_PASS * j;
+        woff[j] = n < N ? 2u * (unsigned)(n * K + 8 * slot) : OOB;
+    }
+    int kh = 0, kw = 0, c0 = 0, k0 = 0;                   // wave-uniform position of the next fetch (K % 64 == 0)
+    auto refresh = [&]() {                                // offsets of tap (kh, kw); everything invalid past K
+        asm volatile("");                                 // keeps the callers' branch
+        const bool live = k0 < K;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+            const bool ok = live && base[j] >= 0 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            voff[j] = ok ? 2u * (unsigned)(base[j] + (hi * a.W + wi) * a.Cin + 8 * slot) : OOB;
+        }
+#pragma unroll
+        for (int j = 0; j < RW; ++j) weff[j] = live ? woff[j] : OOB;
+    };
+    refresh();
+    uint4 rr[NJ];                                         // staging registers: A rows, then W rows
+    auto load_job = [&](int qj) {
+        if (qj < RA)
+            rr[qj] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsa, voff[qj], 2u * (unsigned)c0, 0));
+        else
+            rr[qj] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsw, weff[qj - RA], 2u * (unsigned)k0, 0));
+    };
+    auto next_k = [&]() {
+        k0 += BK;
+        c0 += BK;
+        if (c0 >= a.Cin || k0 >= K) {
+            if (c0 >= a.Cin) { c0 = 0; if (++kw == a.KW) { kw = 0; ++kh; } }
+            refresh();
+        }
+    };
+    const int st_off = srow * LD + 8 * (slot ^ ((srow >> 1) & 7));      // ROWS_PER_PASS is a multiple of 16: same swizzle per pass
+    auto write_job = [&](int qj, int im) {
+        const int rrow = qj < RA ? ROWS_PER_PASS * qj : BM + ROWS_PER_PASS * (qj - RA);
+        *reinterpret_cast<uint4*>(&lds[im + st_off + rrow * LD]) = rr[qj];
+    };
+    // operand fragment of lane (row = lane & 31, k half = lane >> 5) for the 16-wide k group g: logical chunk 2g + half
+    const int lrow = lane & 31, sw = (lrow >> 1) & 7, half = lane >> 5;
+    const int a_row = (wm * FM * 32 + lrow) * LD, b_row = (BM + wn * FN * 32 + lrow) * LD;
+    bf16x8 fr[2][NR];
+    auto read_job = [&](int set, int rj, int g, int im) {
+        const int off = (rj < FM ? a_row + rj * 32 * LD : b_row + (rj - FM) * 32 * LD) + 8 * ((2 * g + half) ^ sw);
+        fr[set][rj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&lds[im + off]));
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                slab[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * EPITCH + j * 32 + (lane & 31)] = acc[i][j][e];
-        __builtin_amdgcn_wave_barrier();
-        const int mb = m0 + (wm * FM + i) * 32;
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // side jobs of MFMA group g: the NR operand reads of the next group, then (g < KB-2 .. ) stage writes / loads
+    auto kstep = [&](int cur, int nxt) {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < NIT; ++t) {
-            const int row = r_in + RPI * t;
-            const int m = mb + row;
-            const float4 v = *reinterpret_cast<const float4*>(&slab[row * EPITCH + 4 * c4]);
-            if (n_ok && m < M) {
-                const size_t o = (size_t)m * ep.ldc + nb;
-                float4 y;
-                y.x = v.x * sc.x + sh.x; y.y = v.y * sc.y + sh.y; y.z = v.z * sc.z + sh.z; y.w = v.w * sc.w + sh.w;
-                if (ep.residual) {
-                    const bf16x4 rs = *reinterpret_cast<const bf16x4*>(ep.residual + o);
-                    y.x += (float)rs[0]; y.y += (float)rs[1]; y.z += (float)rs[2]; y.w += (float)rs[3];
+        for (int g = 0; g < KB; ++g) {
+            const int set = g & 1;
+            // jobs of this group: NR reads, then writes (first half of the step) or loads (second half)
+            constexpr int WPG = (NJ + KB / 2 - 1) / (KB / 2);          // writes (loads) per group
+            constexpr int JOBS = NR + WPG, PER = (JOBS + G - 1) / G;
+#pragma unroll
+            for (int ms = 0; ms < G; ++ms) {
+                const int i = ms / FN, j = ms % FN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[set][i], fr[set][FM + j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                    const int job = ms * PER + u;
+                    if (job < NR) {
+                        if (g + 1 < KB) read_job(set ^ 1, job, g + 1, cur);
+                        else read_job(0, job, 0, nxt);
+                    } else if (job < JOBS) {
+                        const int w = (g % (KB / 2)) * WPG + (job - NR);
+                        if (w < NJ) {
+                            if (g < KB / 2) write_job(w, nxt);
+                            else load_job(w);
+                        }
+                    }
                 }
-                if (ep.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
-                if (ep.out_f32) {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(ep.out) + o) = y;
-                } else {
-                    const bf16x4 ob = {(__bf16)y.x, (__bf16)y.y, (__bf16)y.z, (__bf16)y.w};
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(ep.out) + o) = ob;
-                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g == KB - 2) {
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        next_k();
+    };
+
+#pragma unroll
+    for (int qj = 0; qj < NJ; ++qj) load_job(qj);
+    next_k();
+#pragma unroll
+    for (int qj = 0; qj < NJ; ++qj) write_job(qj, 0);
+#pragma unroll
+    for (int qj = 0; qj < NJ; ++qj) load_job(qj);
+    next_k();
+    __syncthreads();
+#pragma unroll
+    for (int rj = 0; rj < NR; ++rj) read_job(0, rj, 0, 0);
+    const int nk = K / BK;
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        kstep(0, STAGE);
+        kstep(STAGE, 0);
     }
+    if (kt < nk) kstep(0, STAGE);
+    __syncthreads();
+    bf16_tile_epilogue<FM, FN, 2 * STAGE * 2>(acc, lds_raw, ep, m0, n0, M, N, wm, wn, lane, wave);
 }
 
+int g_bf16_fast = 1;     // RPG_TUNE_BF16_FAST: the interleaved buffer-load kernel where eligible
 int g_bf16_bk = 32;      // measured on MI355X at 64 graphs: K step 32 -> 9.97 ms/step, 64 -> 12.5 (the 72-KB LDS image halves occupancy)
 
 template <int BM, int BN, int WM, int WN, int BK>
 void launch_tile(const ConvArgsB& a, const __bf16* w, int M, int N, int K, const EpiB& ep, hipStream_t s) {
     constexpr int lds = 2 * (BM + BN) * (BK + 8) * 2;
     auto kern = conv_bf16_kernel<BM, BN, WM, WN, BK>;
+    if (lds > 64 * 1024) {
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            once = true;
+        }
+    }
+    const int tn = (N + BN - 1) / BN, tm = (M + BM - 1) / BM;
+    hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(NT), lds, s, a, w, M, N, K, ep, tn);
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_fast(const ConvArgsB& a, const __bf16* w, int M, int N, int K, const EpiB& ep, hipStream_t s) {
+    constexpr int lds = 2 * (BM + BN) * 64 * 2;
+    auto kern = conv_bf16_fast_kernel<BM, BN, WM, WN>;
     if (lds > 64 * 1024) {
         static bool once = false;
         if (!once) {
@@ -309,6 +499,7 @@ inline int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1
 namespace rpg {
 
 void bf16_set_bk(int bk) { g_bf16_bk = bk; }
+void bf16_set_fast(int on) { g_bf16_fast = on; }
 
 int launch_conv_bf16(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y,
                      int n, int h, int wd, int cin, int cout, int kh, int kw, int stride, int pad, int relu, int out_f32,
@@ -326,7 +517,15 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
     const __bf16* wp = reinterpret_cast<const __bf16*>(w);
     const int slot = timing_begin(RPG_TIMER_CONV, s);
     const bool big_k = g_bf16_bk == 64 && K >= 128;
-    if (cout <= 64 && M >= 65536) {
+    // the interleaved buffer-load kernel: whole 64-element K steps per kernel tap, 32-bit offsets relative to the
+    // first image of a tile (whose <= 256 rows span at most 256 / (ho*wo) + 2 images)
+    const long span = 256 / ((long)ho * wo) + 2;
+    const bool fast = g_bf16_fast && cin % 64 == 0 && span * h * wd * cin * 2 < (1L << 31) && (long)cout * K * 2 < (1L << 31);
+    if (fast) {
+        if (cout <= 64 && M >= 65536) launch_fast<256, 64, 4, 1>(a, wp, (int)M, cout, (int)K, ep, s);
+        else if (cout <= 64 || (long)((M + 127) / 128) * ((cout + 127) / 128) < 256) launch_fast<64, 64, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);
+        else launch_fast<128, 128, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);
+    } else if (cout <= 64 && M >= 65536) {
         if (big_k) launch_tile<256, 64, 4, 1, 64>(a, wp, (int)M, cout, (int)K, ep, s);
         else launch_tile<256, 64, 4, 1, 32>(a, wp, (int)M, cout, (int)K, ep, s);
     } else if (cout <= 64 || (long)((M + 127) / 128) * ((cout + 127) / 128) < 256) {

@@ -52,6 +52,7 @@ bool wino_enabled();
 bool wino_pays(int n, int h, int w, int cin, int cout);
 void wino_set(int on);
 void wino_split_set(int on);
+void bf16_set_fast(int on);
 // Gathered residual rows added in the epilogue: out[m] += res1[idx1[m]] (+ res2[idx2[m]]), row pitch ld.
 struct GatherRes {
     const float* res1;

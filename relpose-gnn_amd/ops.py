@@ -225,7 +225,7 @@ def timing_read() -> Dict[str, Dict[str, float]]:
     return {name: {"ms": ms[i], "launches": int(cnt[i]), "work": work[i]} for i, name in enumerate(L.TIMER_NAMES)}
 
 
-TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT = 0, 1, 2, 3, 4, 5, 6, 7, 8
+TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 def set_tuning(key: int, value: int) -> None:

@@ -35,9 +35,14 @@ def _rand(*shape, seed=0, scale=1.0):
     (40, 56, 56, 64, 64, 3, 1, 1, True, True, False),     # layer1 shape -> 256x64 tile
     (64, 28, 28, 128, 128, 3, 1, 1, True, True, False),   # 128x128 tile
     (37, 1, 1, 512, 2048, 1, 1, 0, False, False, True),   # the fc as a 1x1 conv on a 1x1 image, fp32 output
+    (3, 13, 17, 192, 72, 3, 2, 1, True, True, False),     # ragged M and N, 3 K steps per tap (odd step count), padding taps
 ])
-def test_conv_bf16(dev, n, h, w, cin, cout, k, stride, pad, res, relu, f32out):
+@pytest.mark.parametrize("fast", [1, 0], ids=["interleaved", "general"])
+def test_conv_bf16(dev, n, h, w, cin, cout, k, stride, pad, res, relu, f32out, fast):
+    """Both bf16 convolution kernels (RPG_TUNE_BF16_FAST: the interleaved buffer-load kernel serves Cin % 64 == 0, the
+    general one everything else, so fast=1 exercises the dispatch and fast=0 forces the general kernel)."""
     from relpose_gnn_amd import ops
+    ops.set_tuning(ops.TUNE_BF16_FAST, fast)
     x = _rand(n, cin, h, w, seed=1).bfloat16()
     wt = _rand(cout, cin, k, k, seed=2, scale=(2.0 / (cin * k * k)) ** 0.5).bfloat16()
     scale = torch.rand(cout, generator=torch.Generator().manual_seed(3)) + 0.5
@@ -52,6 +57,7 @@ def test_conv_bf16(dev, n, h, w, cin, cout, k, stride, pad, res, relu, f32out):
     y = ops.conv2d_bn_act_nhwc_bf16(x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev),
                                     scale.to(dev), shift.to(dev), None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev),
                                     stride=stride, pad=pad, relu=relu, out_f32=f32out)
+    ops.set_tuning(ops.TUNE_BF16_FAST, 1)
     assert y.dtype == (torch.float32 if f32out else torch.bfloat16)
     err = rel_err(y.float().cpu().permute(0, 3, 1, 2), ref)
     assert err < (1e-5 if f32out else 1e-2), err
