@@ -559,7 +559,7 @@ extern "C" size_t rpg_resnet_bf16_workspace_bytes(int n, int h, int w, const int
         if (sz > blk) blk = sz;
     }
     return align_up((size_t)n * h * w * 8 * 2, 256) + align_up((size_t)n * h1 * w1 * planes[0] * 2, 256) +
-           4 * align_up(blk * 2, 256) + align_up((size_t)n * planes[3] * 2, 256);
+           4 * align_up(blk * 2, 256) + align_up((size_t)n * planes[3] * 2, 256) + 7 * rpg::kWorkspaceSkew;
 }
 
 // tensors: per conv {w_ohwi bf16, scale f32, shift f32} (stem Cin padded to 8), then fc weight bf16 [feat][512], bias f32.
@@ -595,7 +595,11 @@ extern "C" int rpg_resnet_forward_bf16(const void* const* tensors, int n_tensors
     }
     char* base = reinterpret_cast<char*>(workspace);
     size_t off = 0;
-    auto take = [&](size_t bytes) { char* p = base + off; off += align_up(bytes, 256); return reinterpret_cast<void*>(p); };
+    auto take = [&](size_t bytes) {
+        char* p = base + off;
+        off += align_up(bytes, 256) + rpg::kWorkspaceSkew;      // see rpg_common.h: de-aliases the HBM channels
+        return reinterpret_cast<void*>(p);
+    };
     void* in8 = take((size_t)n * h * w * 8 * 2);
     void* stem = take((size_t)n * h1 * w1 * planes[0] * 2);
     void* buf[4];

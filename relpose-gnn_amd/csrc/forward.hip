@@ -22,7 +22,7 @@ struct Carver {
     template <class T>
     T* take(size_t count) {
         T* p = reinterpret_cast<T*>(base + off);
-        off += align_up(count * sizeof(T), 256);
+        off += align_up(count * sizeof(T), 256) + rpg::kWorkspaceSkew;
         return p;
     }
 };
@@ -49,7 +49,7 @@ ResnetPlan plan_resnet(int n, int h, int w, const int* planes) {
     p.blk = blk;
     p.pool = (size_t)n * planes[3];
     p.total_bytes = align_up(p.in4 * 4, 256) + align_up(p.stem * 4, 256) + 4 * align_up(p.blk * 4, 256) +
-                    align_up(p.pool * 4, 256);
+                    align_up(p.pool * 4, 256) + 7 * rpg::kWorkspaceSkew;
     return p;
 }
 
@@ -168,15 +168,16 @@ struct GnnPlan {
 size_t gnn_bytes(int n, int e, int d) {
     const size_t c = d / 8;
     size_t b = 0;
-    b += align_up((size_t)4 * e * 8, 256);                 // ends
-    b += align_up((size_t)(n + 1) * 4, 256);               // rowptr
-    b += align_up((size_t)n * 4, 256);                     // cursor
-    b += align_up((size_t)e * 4, 256);                     // perm
-    b += 5 * align_up((size_t)e * d * 4, 256);             // e0, e1, hidden, msg, att
-    b += align_up((size_t)e * 3 * c * 4, 256);             // g|theta|phi
-    b += align_up((size_t)e * c * 4, 256);                 // y
-    b += 4 * align_up((size_t)n * d * 4, 256);             // agg, node hidden, x ping-pong
-    b += align_up((size_t)n * 3 * d * 4, 256);             // per-node partial products of the split Linears
+    auto add = [&](size_t bytes, int count = 1) { b += count * (align_up(bytes, 256) + rpg::kWorkspaceSkew); };
+    add((size_t)4 * e * 8);                 // ends
+    add((size_t)(n + 1) * 4);               // rowptr
+    add((size_t)n * 4);                     // cursor
+    add((size_t)e * 4);                     // perm
+    add((size_t)e * d * 4, 5);              // e0, e1, hidden, msg, att
+    add((size_t)e * 3 * c * 4);             // g|theta|phi
+    add((size_t)e * c * 4);                 // y
+    add((size_t)n * d * 4, 4);              // agg, node hidden, x ping-pong
+    add((size_t)n * 3 * d * 4);             // per-node partial products of the split Linears
     return b;
 }
 }  // namespace

@@ -43,6 +43,12 @@ int launch_conv(const float* x, const float* w, const float* scale, const float*
                 hipStream_t s, int alg_cin = 0 /* channels counted as algorithmic work; 0 = cin */);
 int launch_conv_wino(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
                      float* y, int n, int h, int w, int cin, int cout, int relu, hipStream_t s);
+// Workspace carving: every sub-buffer is followed by this many bytes of padding.  The activation buffers of a layer are
+// whole MiB apart otherwise (256 images x 28 x 28 x 128 x 4 B = 98 MiB), so the input, residual and output streams of
+// a convolution hit the same HBM channels in lock-step: measured on the layer-2 Winograd convolution, 323 us with
+// 2-MiB-congruent buffers vs 272 us with >= 68 KB of skew between them (tools/probes/alias_probe.py).
+constexpr size_t kWorkspaceSkew = 260 * 1024 + 4096;
+
 // per-stream scratch for split-K partial tiles (grown on demand; consumers run in stream order) and the CU count
 float* stream_scratch(hipStream_t s, size_t bytes);
 int num_cus();

@@ -166,7 +166,9 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         key = (n, e, d, feat.device)
         ent = self._gnn_ws.get(slot)
         if ent is None or ent[0] != key:
-            ent = (key, torch.empty(lib.rpg_gnn_workspace_bytes(n, e, d), dtype=torch.uint8, device=feat.device))
+            skew = (int(slot) % 7) * 132 * 1024 if isinstance(slot, int) else 0      # see resnet.EncoderRunner: de-aliases the slots
+            raw = torch.empty(lib.rpg_gnn_workspace_bytes(n, e, d) + skew, dtype=torch.uint8, device=feat.device)
+            ent = (key, raw[skew:])
             self._gnn_ws[slot] = ent
         ws = ent[1]
         rc = lib.rpg_gnn_forward_f32(self._gnn_ptrs, len(self._gnn_packed), feat.data_ptr(), esrc_ptr, edst_ptr, node_off, n,

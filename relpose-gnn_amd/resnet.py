@@ -86,7 +86,11 @@ class EncoderRunner:
         ent = self._ws.get(slot)          # one workspace per concurrent stream slot, kept for the last shape seen
         if ent is None or ent[0] != key:
             nbytes = (lib.rpg_resnet_bf16_workspace_bytes if bf16 else lib.rpg_resnet_workspace_bytes)(n, h, w, planes_c)
-            ent = (key, torch.empty(nbytes, dtype=torch.uint8, device=x.device))
+            # concurrent stream slots get workspaces that start at different offsets within a 2-MiB window: torch hands
+            # out 2-MiB-aligned blocks and identically laid-out workspaces would put both streams on the same HBM channels
+            skew = (int(slot) % 7) * 132 * 1024 if isinstance(slot, int) else 0
+            raw = torch.empty(nbytes + skew, dtype=torch.uint8, device=x.device)
+            ent = (key, raw[skew:])
             self._ws[slot] = ent
         ws = ent[1]
         feat = torch.empty((n, feat_dim), dtype=torch.float32, device=x.device)
