@@ -233,7 +233,8 @@ def main():
                 "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "wino43_conv8_kernel (3x3/stride-1 conv + BN (+residual) + ReLU as 1-D Winograd F(4,3) on "
-                          "v_mfma_f32_32x32x2_f32; 29 of the 36 ResNet34 convolutions)",
+                          "v_mfma_f32_32x32x2_f32; 29 of the 36 ResNet34 convolutions); a launch = the <false> main kernel "
+                          "plus, on layers with a tail, its split-K <true> kernel and wino43_fixup_kernel",
                 "launches": c["launches"], "avg_launch_ms": round(c["ms"] / c["launches"], 4),
                 "alg_gflop_per_launch": round(c["work"] / c["launches"] / 1e9, 3),
                 "note": "achieved = ALGORITHMIC (direct-convolution) FLOP / duration; F(4,3) executes ~0.5-0.57x of them "
