@@ -31,6 +31,26 @@ def test_library_exports_every_declared_symbol():
         _lib.check(_lib.RPG_ERR_BAD_ARG, "x")
 
 
+def test_tuning_and_timer_constants_match_the_header():
+    """ops.TUNE_* and the timer classes are the header's #defines (they are passed across the ABI as plain ints), and
+    rpg_set_tuning validates keys / values on the host side (no GPU involved)."""
+    from relpose_gnn_amd import _lib, ops
+    hdr = open(os.path.join(ROOT, "include", "relpose_gnn_hip.h")).read()
+    defs = {k: int(v) for k, v in re.findall(r"#define\s+(RPG_[A-Z0-9_]+)\s+(-?\d+)\b", hdr)}
+    tune = {k[len("RPG_TUNE_"):]: v for k, v in defs.items() if k.startswith("RPG_TUNE_")}
+    assert len(set(tune.values())) == len(tune)                       # no two knobs share a key
+    for name, key in tune.items():
+        assert getattr(ops, "TUNE_" + name) == key, name
+    assert {k for k in dir(ops) if k.startswith("TUNE_")} == {"TUNE_" + k for k in tune}
+    lib = _lib.lib()
+    assert lib.rpg_set_tuning(12345, 0) == _lib.RPG_ERR_BAD_ARG       # unknown key
+    assert lib.rpg_set_tuning(defs["RPG_TUNE_BK"], 24) == _lib.RPG_ERR_BAD_ARG
+    assert lib.rpg_set_tuning(defs["RPG_TUNE_WINOGRAD"], 7) == _lib.RPG_ERR_BAD_ARG
+    for name, key in tune.items():                                    # defaults are accepted and restore the defaults
+        default = {"TILE": -1, "BK": 0, "BF16_BK": 32}.get(name, 1)
+        assert lib.rpg_set_tuning(key, default) == 0, name
+
+
 def test_state_dict_contract_matches_reference_inventory():
     from relpose_gnn_amd.posenet import PoseNetX_R2
     from relpose_gnn_amd.resnet import resnet34
