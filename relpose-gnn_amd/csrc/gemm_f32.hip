@@ -12,9 +12,16 @@
 // ds_read_b128 land on 16 distinct 4-bank slots).  A lane (i, h) reads 4 consecutive k of row i at offset
 // 4h and feeds them to 4 MFMAs, so the two k-slices of one MFMA are k and k+4: a permutation of the
 // summation order that A and W share.  Global->LDS staging goes through registers (the im2col / gather
-// addressing is per-row, and the padded pitch rules out LDS-DMA); the loads for step t+1 are issued before
-// the MFMAs of step t and written to the other buffer after them, one barrier per step.
-// Workgroup ids are remapped so that the tiles sharing an A row-panel run on one XCD (shared L2).
+// addressing is per-row, and the padded pitch rules out LDS-DMA), one barrier per step.  Two main loops:
+//   * tile_mainloop_b + ConvLoaderB / ConvLoaderTap / GatherLoaderB (whenever every K segment is a multiple of BK: all
+//     the shapes of the hot path): raw buffer loads with K-invariant lane offsets and the K position in the scalar
+//     offset, and every load / LDS access placed singly behind an MFMA, because VALU time does not hide behind f32
+//     MFMAs on gfx950 and a wave issues in order (tools/probes/mfma_shadow_probe.hip);
+//   * tile_mainloop + ConvLoader / GatherLoader: any shape (ragged K, unaligned segments), loads before / stage
+//     writes after the MFMAs of a step.
+// Tiles: 128x128, 256x64 (Cout = 64), 128x64 and 64x64 (small problems); a stream-K pass + fix-up kernel balances the
+// tiles that do not fill a round of resident workgroups.  Workgroup ids are remapped so that the tiles sharing an A
+// row-panel run on one XCD (shared L2).
 #include <map>
 #include <mutex>
 

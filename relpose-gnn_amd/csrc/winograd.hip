@@ -11,12 +11,14 @@
 //
 // So one convolution = 6 independent GEMMs  [tiles x 3*Cin] * [3*Cin x Cout]  whose accumulators a lane combines
 // in registers at the end (the output transform is lane-local: the MFMA C layout puts the same (tile, cout) element
-// of all 6 products in the same lane).  Workgroup = 4 waves on 64 tiles (= 256 output pixels) x 64 output channels;
-// a wave owns 32 tiles x 32 channels x 6 positions = 6 accumulators of 32x32.  K advances 16 at a time through ONE
-// LDS buffer pair (A: V[6][64][16], B: U[6][64][16] = 48 KB, chunk-swizzled; two workgroups per CU by VGPRs): the raw pixels / weights of
-// step t+1 are fetched into registers while the 48 MFMAs of step t run, the input transform is applied when they
-// are written to LDS between two barriers.  Epilogue: output transform, then the same LDS-transposed 16-byte
-// BatchNorm / residual / ReLU / store as the direct kernel, two of the four pixel columns at a time.
+// of all 6 products in the same lane); a wave owns 32 tiles x 32 channels x 6 positions = 6 accumulators of 32x32.
+// Two kernels share the addressing, the LDS layout (64-byte rows of four 16-byte chunks, XOR-swizzled by row) and
+// the epilogue (output transform, LDS transpose, BatchNorm / residual / ReLU through raw buffer accesses):
+//   * wino43_conv8_kernel (the one that matters): 8 waves on 128 tiles x 64 channels, two LDS images of a 16-wide K
+//     step, one barrier per step, every load / LDS access placed singly behind an MFMA; <true> is its split-K
+//     variant for the tiles beyond the last full round of CUs, finished by wino43_fixup_kernel;
+//   * wino43_conv_kernel: 4 waves on 64 tiles x 64 channels, one LDS image, two workgroups per CU: small grids.
+// The design rules come from tools/probes/mfma_shadow_probe.hip: VALU time does not hide behind f32 MFMAs on gfx950.
 //
 // Reference op replaced: nn.Conv2d(3x3, stride 1, pad 1) + nn.BatchNorm2d (eval) (+ identity) + ReLU of a torchvision
 // BasicBlock, reached from /root/reference/python/niantic/modules/posenet.py:1037.
