@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
+BF16_MATRIX_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA (MI355X_MICROARCH.md)
 F32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 HBM_PEAK_GBS = 8000.0
 NODES, IMG = 8, 224
@@ -45,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU the batch is spread over in the timed region")
+    ap.add_argument("--gnn-dtype", choices=("f32", "bf16"), default="f32",
+                    help="bf16: the GNN's Linears on the bf16 matrix pipe too (only meaningful with --encoder-dtype bf16)")
     ap.add_argument("--bf16-bk", type=int, default=0, help="K step of the bf16 conv kernel (32|64; 0 = library default)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="rpg_set_tuning(KEY, VALUE) before the run, for A/B experiments (e.g. --tune 8=0: no Winograd split-K tail)")
@@ -139,6 +142,7 @@ def main():
     model = model.to(dev).eval()
     model.hip_streams = args.streams
     model.encoder_dtype = args.encoder_dtype
+    model.gnn_dtype = args.gnn_dtype
     if args.bf16_bk:
         ops.set_tuning(ops.TUNE_BF16_BK, args.bf16_bk)
     for kv in args.tune:
@@ -204,7 +208,8 @@ def main():
             "metric": "graphs/sec (8-node fully-connected, 224x224)", "value": round(graphs / elapsed, 2),
             "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.encoder_dtype == "f32" else "bf16 encoder (f32 accumulate) + f32 GNN",
+            "vs_baseline": None, "dtype": "f32" if args.encoder_dtype == "f32" else
+            ("bf16 encoder (f32 accumulate) + f32 GNN" if args.gnn_dtype == "f32" else "bf16 encoder + bf16 GNN Linears (f32 accumulate)"),
             "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]: batch={B} 8-node fully-connected graphs per GPU, 224x224 RGB, "
                                    "fp32, ResNet34 + GNN (D=2048, gnn_recursion=2, droprate=0, eval), random-init weights",
@@ -215,10 +220,17 @@ def main():
         if kt is not None and args.encoder_dtype == "bf16" and kt["conv"]["launches"]:
             c = kt["conv"]
             line["config"]["workload"] = line["config"]["workload"].replace("configs[1]", "configs[2]").replace(", fp32,", ", bf16 encoder,")
-            line["roofline"] = {"bound": "hbm", "kernel": "conv_bf16_kernel (implicit-GEMM conv, v_mfma_f32_32x32x16_bf16)",
-                                "achieved_tflops": round(c["work"] / (c["ms"] * 1e-3) / 1e12, 2), "launches": c["launches"],
-                                "avg_launch_ms": round(c["ms"] / c["launches"], 4), "traffic": None,
-                                "note": "bf16 matrix peak is 2.5 PFLOP/s: these convolutions are memory/latency-bound"}
+            tf = c["work"] / (c["ms"] * 1e-3) / 1e12
+            line["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": BF16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(tf / BF16_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                                "kernel": "conv_bf16_fast_kernel / conv_bf16_kernel (implicit-GEMM conv, v_mfma_f32_32x32x16_bf16)",
+                                "launches": c["launches"], "avg_launch_ms": round(c["ms"] / c["launches"], 4),
+                                "note": "128x128-tile kernels: the layer-1 shapes are HBM-bound at this rate (DESIGN.md), the "
+                                        "others are bound by per-tile prologue / epilogue at 9-72 K steps per tile"}
+            if kt["linear"]["launches"]:
+                v = kt["linear"]
+                line["other_kernels"] = {"linear": {"achieved": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                                                    "launches": v["launches"], "avg_launch_ms": round(v["ms"] / v["launches"], 5)}}
         elif kt is not None and kt["conv_wino"]["launches"]:
             c = kt["conv_wino"]
             ach = c["work"] / (c["ms"] * 1e-3) / 1e12

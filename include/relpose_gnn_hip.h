@@ -170,6 +170,27 @@ int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, const float*
                         float* node_out, float* edge_out, int32_t* status, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* The same forward with the Linears on the bf16 matrix pipe (BASELINE configs[2]/[4] "bf16 activations"): a Linear's
+ * input is rounded to bf16 on the fly, its weight is read from weights_bf16, accumulation / bias / residual / output
+ * stay fp32, and everything that is not a GEMM (attention rows, scatter-mean, heads) is the fp32 kernel of above.
+ * Needs the 26-tensor (split) table and d % 64 == 0.  weights_bf16: HOST array of 10 device pointers to bf16 [out][in]
+ * matrices, in this order (params.pack_gnn_bf16): tensors[22] (proj node blocks), tensors[23] (edge_mlp.0 | mlp.0 node
+ * blocks), tensors[24] (edge_mlp.0 edge block), edge_mlp.2, tensors[25] (mlp.0 edge block), mlp.2, att.{g|theta|phi},
+ * att.W, mlp_updating.0, mlp_updating.2.  Not part of the fp32 parity claim: tolerance in tests/test_hip_bf16.py.   */
+int rpg_gnn_forward_bf16(const float* const* tensors, int n_tensors, const void* const* weights_bf16, int n_bf16,
+                         const float* feat, const int64_t* src, const int64_t* dst, int64_t node_offset, int n, int e, int d,
+                         int gnn_recursion, float* abs_pose, float* rel_pose, float* node_out, float* edge_out,
+                         int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Building blocks of the above.  rpg_f32_to_bf16: dst[r][col_off + c] = bf16(src[r][c]) for c < cols (cols, col_off,
+ * ld_dst % 8 == 0).  rpg_linear_bf16: out[m][n_out] (fp32) = act(a[m][k] (bf16) * weight[n_out][k]^T (bf16) + bias +
+ * residual[(res_idx ? res_idx[r] : r) * ldr + :] + residual2[res2_idx[r] * ldr + :]); k % 8 == 0, n_out % 4 == 0.
+ * Replaces nn.Linear (+ the gathered node terms of the split formulation), my_gnn_layer.py:236-239,304-311.         */
+int rpg_f32_to_bf16(const float* src, int ld_src, void* dst, int ld_dst, int col_off, long rows, int cols, void* stream);
+int rpg_linear_bf16(const void* a, const void* weight, const float* bias, const float* residual, const int64_t* res_idx,
+                    const float* residual2, const int64_t* res2_idx, int ldr, float* out, int m, int k, int n_out,
+                    int relu, void* stream);
+
 /* ------------------------------------------------------------------------------------------- */
 /* Per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline).  */
 /* ------------------------------------------------------------------------------------------- */

@@ -23,7 +23,7 @@ SYMBOLS = (
     "rpg_attention_rows_f32", "rpg_scatter_mean_f32", "rpg_pose_heads_f32", "rpg_gnn_workspace_bytes",
     "rpg_gnn_forward_f32", "rpg_timing_enable", "rpg_timing_read", "rpg_set_tuning", "rpg_knn_graph_f32", "rpg_wino43_transform_weights_f32",
     "rpg_conv3x3_wino43_bn_act_nhwc_f32", "rpg_conv2d_bn_act_nhwc_bf16", "rpg_resnet_bf16_workspace_bytes",
-    "rpg_resnet_forward_bf16",
+    "rpg_resnet_forward_bf16", "rpg_gnn_forward_bf16", "rpg_f32_to_bf16", "rpg_linear_bf16",
 )
 
 
@@ -61,6 +61,10 @@ def _declare(lib: C.CDLL) -> None:
     lib.rpg_gnn_workspace_bytes.restype = _sz
     lib.rpg_gnn_forward_f32.argtypes = [C.POINTER(_vp), _i, _vp, _vp, _vp, C.c_int64, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                                         _vp, _vp, _sz, _vp]
+    lib.rpg_gnn_forward_bf16.argtypes = [C.POINTER(_vp), _i, C.POINTER(_vp), _i, _vp, _vp, _vp, C.c_int64, _i, _i, _i, _i, _vp,
+                                         _vp, _vp, _vp, _vp, _vp, _sz, _vp]
+    lib.rpg_f32_to_bf16.argtypes = [_vp, _i, _vp, _i, _i, C.c_long, _i, _vp]
+    lib.rpg_linear_bf16.argtypes = [_vp] * 7 + [_i, _vp, _i, _i, _i, _i, _vp]
     lib.rpg_timing_enable.argtypes = [_i]
     lib.rpg_set_tuning.argtypes = [_i, _i]
     lib.rpg_conv2d_bn_act_nhwc_bf16.argtypes = [_vp] * 6 + [_i] * 11 + [_vp]

@@ -28,6 +28,13 @@ struct EpiB {
     int ldc;
     int relu;
     int out_f32;
+    // fp32 residual rows for the bf16 Linears of the GNN: row m adds res_f32[(res_idx ? res_idx[m] : m) * ldr + n]
+    // and, if given, res2_f32[res2_idx[m] * ldr + n]
+    const float* res_f32 = nullptr;
+    const int64_t* res_idx = nullptr;
+    const float* res2_f32 = nullptr;
+    const int64_t* res2_idx = nullptr;
+    int ldr = 0;
 };
 
 struct ConvArgsB {
@@ -76,6 +83,15 @@ __device__ __forceinline__ void bf16_tile_epilogue(f32x16 (&acc)[FM][FN], unsign
                 if (ep.residual) {
                     const bf16x4 rs = *reinterpret_cast<const bf16x4*>(ep.residual + o);
                     y.x += (float)rs[0]; y.y += (float)rs[1]; y.z += (float)rs[2]; y.w += (float)rs[3];
+                }
+                if (ep.res_f32) {
+                    const size_t ro = (size_t)(ep.res_idx ? ep.res_idx[m] : (int64_t)m) * ep.ldr + nb;
+                    const float4 rs = *reinterpret_cast<const float4*>(ep.res_f32 + ro);
+                    y.x += rs.x; y.y += rs.y; y.z += rs.z; y.w += rs.w;
+                    if (ep.res2_f32) {
+                        const float4 r2 = *reinterpret_cast<const float4*>(ep.res2_f32 + (size_t)ep.res2_idx[m] * ep.ldr + nb);
+                        y.x += r2.x; y.y += r2.y; y.z += r2.z; y.w += r2.w;
+                    }
                 }
                 if (ep.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
                 if (ep.out_f32) {
@@ -501,6 +517,58 @@ namespace rpg {
 void bf16_set_bk(int bk) { g_bf16_bk = bk; }
 void bf16_set_fast(int on) { g_bf16_fast = on; }
 
+// fp32 [rows][ld_src] (first `cols` columns) -> bf16 dst[rows][ld_dst] at column offset col_off (cols % 8 == 0)
+__global__ __launch_bounds__(NT) void f32_to_bf16_kernel(const float* __restrict__ src, int ld_src, __bf16* __restrict__ dst,
+                                                         int ld_dst, int col_off, long total8, int cols8) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total8; i += (long)gridDim.x * NT) {
+        const long r = i / cols8;
+        const int c = (int)(i - r * cols8) * 8;
+        const float4 a = *reinterpret_cast<const float4*>(src + r * ld_src + c);
+        const float4 b = *reinterpret_cast<const float4*>(src + r * ld_src + c + 4);
+        const bf16x8 v = {(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+        *reinterpret_cast<uint4*>(dst + r * ld_dst + col_off + c) = __builtin_bit_cast(uint4, v);
+    }
+}
+
+int launch_f32_to_bf16(const float* src, int ld_src, void* dst, int ld_dst, int col_off, long rows, int cols, hipStream_t s) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || (cols & 7) || (ld_src & 3) || (ld_dst & 7) || (col_off & 7) ||
+        !aligned16(src) || !aligned16(dst))
+        return RPG_ERR_BAD_ARG;
+    const long total8 = rows * (cols / 8);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(capped_grid(total8)), dim3(NT), 0, s, src, ld_src,
+                       reinterpret_cast<__bf16*>(dst), ld_dst, col_off, total8, cols / 8);
+    RPG_CHECK_LAUNCH("f32_to_bf16");
+    return RPG_OK;
+}
+
+// out[m][n_out] (fp32) = act(a[m][k] (bf16) * w[n_out][k]^T (bf16) + bias + residual rows): the Linear of the bf16 GNN
+// as a 1x1 convolution over an m-pixel "image"; residual: fp32 rows, optionally gathered (see EpiB).
+int launch_linear_bf16(const void* a, const void* w, const float* bias, const float* res, const int64_t* res_idx,
+                       const float* res2, const int64_t* res2_idx, int ldr, float* out, int m, int k, int n_out, int relu,
+                       hipStream_t s) {
+    if (!a || !w || !out || m <= 0 || k <= 0 || n_out <= 0 || (k & 7) || (n_out & 3) || !aligned16(a) || !aligned16(w) ||
+        !aligned16(out) || (bias && !aligned16(bias)) || (res && (!aligned16(res) || (ldr & 3) || ldr < n_out)) ||
+        (res2 && (!res || !res2_idx || !aligned16(res2))))
+        return RPG_ERR_BAD_ARG;
+    ConvArgsB ca{reinterpret_cast<const __bf16*>(a), 1, 1, k, 1, 1, 1, 0, 1, 1};
+    EpiB ep{nullptr, bias, nullptr, out, n_out, relu, 1};
+    ep.res_f32 = res; ep.res_idx = res_idx; ep.res2_f32 = res2; ep.res2_idx = res2_idx; ep.ldr = ldr;
+    const __bf16* wp = reinterpret_cast<const __bf16*>(w);
+    const int slot = timing_begin(RPG_TIMER_LINEAR, s);
+    const bool fast = g_bf16_fast && k % 64 == 0 && 258L * k * 2 < (1L << 31) && (long)n_out * k * 2 < (1L << 31);
+    const long t128 = (long)((m + 127) / 128) * ((n_out + 127) / 128);
+    if (fast) {
+        if (t128 >= 192) launch_fast<128, 128, 2, 2>(ca, wp, m, n_out, k, ep, s);
+        else launch_fast<64, 64, 2, 2>(ca, wp, m, n_out, k, ep, s);
+    } else {
+        if (t128 >= 192) launch_tile<128, 128, 2, 2, 32>(ca, wp, m, n_out, k, ep, s);
+        else launch_tile<64, 64, 2, 2, 32>(ca, wp, m, n_out, k, ep, s);
+    }
+    timing_end(slot, 2.0 * (double)m * n_out * (double)k, s);
+    RPG_CHECK_LAUNCH("linear_bf16");
+    return RPG_OK;
+}
+
 int launch_conv_bf16(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y,
                      int n, int h, int wd, int cin, int cout, int kh, int kw, int stride, int pad, int relu, int out_f32,
                      hipStream_t s) {
@@ -659,4 +727,16 @@ extern "C" int rpg_resnet_forward_bf16(const void* const* tensors, int n_tensors
     // fc as a 1x1 convolution on a 1x1 image: [n][1][1][cin] x [feat][1][1][cin], bias in `shift`, fp32 output
     return rpg::launch_conv_bf16(pool, tensors[ti], nullptr, (const float*)tensors[ti + 1], nullptr, feat, n, 1, 1, cin,
                                  feat_dim, 1, 1, 1, 0, 0, 1, s);
+}
+
+extern "C" int rpg_f32_to_bf16(const float* src, int ld_src, void* dst, int ld_dst, int col_off, long rows, int cols,
+                               void* stream) {
+    return rpg::launch_f32_to_bf16(src, ld_src, dst, ld_dst, col_off, rows, cols, rpg::as_stream(stream));
+}
+
+extern "C" int rpg_linear_bf16(const void* a, const void* weight, const float* bias, const float* residual,
+                               const int64_t* res_idx, const float* residual2, const int64_t* res2_idx, int ldr, float* out,
+                               int m, int k, int n_out, int relu, void* stream) {
+    return rpg::launch_linear_bf16(a, weight, bias, residual, res_idx, residual2, res2_idx, ldr, out, m, k, n_out, relu,
+                                   rpg::as_stream(stream));
 }

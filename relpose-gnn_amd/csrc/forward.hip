@@ -178,6 +178,7 @@ size_t gnn_bytes(int n, int e, int d) {
     add((size_t)e * c * 4);                 // y
     add((size_t)n * d * 4, 4);              // agg, node hidden, x ping-pong
     add((size_t)n * 3 * d * 4);             // per-node partial products of the split Linears
+    add((size_t)(e > 2 * n ? e : 2 * n) * d * 2);   // bf16 image of a Linear's input (bf16 GNN only)
     return b;
 }
 }  // namespace
@@ -187,17 +188,24 @@ extern "C" size_t rpg_gnn_workspace_bytes(int n, int e, int d) {
     return gnn_bytes(n, e, d);
 }
 
-extern "C" int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, const float* feat, const int64_t* esrc,
-                                   const int64_t* edst, int64_t node_offset, int n, int e, int d, int gnn_recursion, float* abs_pose,
-                                   float* rel_pose, float* node_out, float* edge_out, int32_t* status, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
+namespace {
+// wb: null (every Linear in fp32), or the bf16 images of the 10 GEMM weights of the split formulation, in the order
+// of BfWeight (then the Linears run on v_mfma_f32_32x32x16_bf16 with bf16 inputs / weights, fp32 accumulation, fp32
+// bias / residual / output; everything that is not a GEMM stays fp32)
+enum BfWeight { B_PROJN, B_NODE3, B_EDGE0E, B_EDGE2, B_MSG0E, B_MSG2, B_GTP, B_ATTW, B_UPD0, B_UPD2, B_COUNT };
+
+int gnn_forward_impl(const float* const* tensors, int n_tensors, const void* const* wb, const float* feat, const int64_t* esrc,
+                     const int64_t* edst, int64_t node_offset, int n, int e, int d, int gnn_recursion, float* abs_pose,
+                     float* rel_pose, float* node_out, float* edge_out, int32_t* status, void* workspace,
+                     size_t workspace_bytes, void* stream) {
     if (!tensors || (n_tensors != T_COUNT && n_tensors != T_COUNT_SPLIT) || !feat || !esrc || !edst || !abs_pose || !rel_pose || !status || !workspace ||
         n <= 0 || e <= 0 || d <= 0 || (d & 31) || gnn_recursion < 0)
         return RPG_ERR_BAD_ARG;
     for (int i = 0; i < n_tensors; ++i)
         if (!tensors[i]) return RPG_ERR_BAD_ARG;
     if (workspace_bytes < gnn_bytes(n, e, d)) return RPG_ERR_WORKSPACE;
-    const bool split = (n_tensors == T_COUNT_SPLIT) && rpg::gnn_split_enabled();
+    const bool split = (n_tensors == T_COUNT_SPLIT) && (wb || rpg::gnn_split_enabled());
+    if (wb && !split) return RPG_ERR_BAD_ARG;            // the bf16 Linears exist for the split formulation only
     hipStream_t s = rpg::as_stream(stream);
     const int c = d / 8;
 
@@ -216,6 +224,7 @@ extern "C" int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, c
     float* nhid = cv.take<float>((size_t)n * d);
     float* xbuf[2] = {cv.take<float>((size_t)n * d), cv.take<float>((size_t)n * d)};
     float* node3 = cv.take<float>((size_t)n * 3 * d);
+    void* abf = cv.take<unsigned short>((size_t)(e > 2 * n ? e : 2 * n) * d);
 
     int rc;
     if ((rc = rpg_graph_prepare(esrc, edst, node_offset, e, n, ends, rowptr, cursor, perm, status, stream)) != RPG_OK) return rc;
@@ -233,6 +242,25 @@ extern "C" int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, c
         g.a[1] = a1; g.idx[1] = i1; g.ld[1] = w1; g.width[1] = w1;
         g.a[2] = a2; g.idx[2] = i2; g.ld[2] = w2; g.width[2] = w2;
         for (int i = 0; i < 3; ++i) g.rows[i] = g.idx[i] ? (n > e ? n : e) : 0;       // node / edge ids index n- or e-row arrays
+        if (wb) {            // bf16: only ungathered sources reach here (split formulation); concatenate them in bf16
+            int bw = -1;
+            switch (wt) {
+                case T_EDGE2_W: bw = B_EDGE2; break;
+                case T_MSG2_W: bw = B_MSG2; break;
+                case T_GTP_W: bw = B_GTP; break;
+                case T_ATTW_W: bw = B_ATTW; break;
+                case T_UPD0_W: bw = B_UPD0; break;
+                case T_UPD2_W: bw = B_UPD2; break;
+                default: return RPG_ERR_BAD_ARG;
+            }
+            const int k = w0 + (ns > 1 ? w1 : 0);
+            if (ns > 2 || i0 || i1) return RPG_ERR_BAD_ARG;
+            int r2;
+            if ((r2 = rpg::launch_f32_to_bf16(a0, w0, abf, k, 0, m, w0, s)) != RPG_OK) return r2;
+            if (ns > 1 && (r2 = rpg::launch_f32_to_bf16(a1, w1, abf, k, w0, m, w1, s)) != RPG_OK) return r2;
+            return rpg::launch_linear_bf16(abf, wb[bw], tensors[wt + 1], residual, nullptr, nullptr, nullptr, n_out, out, m, k,
+                                           n_out, relu, s);
+        }
         return rpg::launch_linear(g, tensors[wt], tensors[wt + 1], residual, out, m, n_out, relu, s);
     };
 
@@ -241,6 +269,12 @@ extern "C" int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, c
     auto node_gemm = [&](const float* xin, int wt, int n_out) {
         rpg::GatherSrc g{};
         g.n = 1; g.a[0] = xin; g.idx[0] = nullptr; g.ld[0] = d; g.width[0] = d;
+        if (wb) {
+            int r2;
+            if ((r2 = rpg::launch_f32_to_bf16(xin, d, abf, d, 0, n, d, s)) != RPG_OK) return r2;
+            return rpg::launch_linear_bf16(abf, wb[wt == T_PROJN_W ? B_PROJN : B_NODE3], nullptr, nullptr, nullptr, nullptr,
+                                           nullptr, 0, node3, n, d, n_out, 0, s);
+        }
         return rpg::launch_linear(g, tensors[wt], nullptr, nullptr, node3, n, n_out, 0, s);
     };
     auto edge_gemm = [&](const float* ein, int wt, int bias_t, const float* r1, const int64_t* i1, const float* r2,
@@ -248,6 +282,12 @@ extern "C" int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, c
         rpg::GatherSrc g{};
         g.n = 1; g.a[0] = ein; g.idx[0] = nullptr; g.ld[0] = d; g.width[0] = d;
         const rpg::GatherRes gr{r1, i1, r2, i2, 3 * d};
+        if (wb) {
+            int rcb;
+            if ((rcb = rpg::launch_f32_to_bf16(ein, d, abf, d, 0, e, d, s)) != RPG_OK) return rcb;
+            return rpg::launch_linear_bf16(abf, wb[wt == T_EDGE0E_W ? B_EDGE0E : B_MSG0E], tensors[bias_t], r1, i1, r2, i2, 3 * d,
+                                           out, e, d, d, 1, s);
+        }
         return rpg::launch_linear(g, tensors[wt], tensors[bias_t], nullptr, out, e, d, 1, s, &gr);
     };
 
@@ -302,4 +342,24 @@ extern "C" int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, c
     // heads (droprate == 0, use_AP)                                                     posenet.py:1077-1091
     if ((rc = rpg_pose_heads_f32(x, tensors[T_HEADN_W], tensors[T_HEADN_B], n, d, abs_pose, stream)) != RPG_OK) return rc;
     return rpg_pose_heads_f32(ecur, tensors[T_HEADE_W], tensors[T_HEADE_B], e, d, rel_pose, stream);
+}
+}  // namespace
+
+extern "C" int rpg_gnn_forward_f32(const float* const* tensors, int n_tensors, const float* feat, const int64_t* esrc,
+                                   const int64_t* edst, int64_t node_offset, int n, int e, int d, int gnn_recursion, float* abs_pose,
+                                   float* rel_pose, float* node_out, float* edge_out, int32_t* status, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    return gnn_forward_impl(tensors, n_tensors, nullptr, feat, esrc, edst, node_offset, n, e, d, gnn_recursion, abs_pose, rel_pose,
+                            node_out, edge_out, status, workspace, workspace_bytes, stream);
+}
+
+extern "C" int rpg_gnn_forward_bf16(const float* const* tensors, int n_tensors, const void* const* weights_bf16, int n_bf16,
+                                    const float* feat, const int64_t* esrc, const int64_t* edst, int64_t node_offset, int n, int e,
+                                    int d, int gnn_recursion, float* abs_pose, float* rel_pose, float* node_out, float* edge_out,
+                                    int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!weights_bf16 || n_bf16 != B_COUNT || (d & 63)) return RPG_ERR_BAD_ARG;
+    for (int i = 0; i < B_COUNT; ++i)
+        if (!weights_bf16[i]) return RPG_ERR_BAD_ARG;
+    return gnn_forward_impl(tensors, n_tensors, weights_bf16, feat, esrc, edst, node_offset, n, e, d, gnn_recursion, abs_pose,
+                            rel_pose, node_out, edge_out, status, workspace, workspace_bytes, stream);
 }

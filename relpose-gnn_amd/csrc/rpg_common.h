@@ -59,6 +59,10 @@ bool wino_pays(int n, int h, int w, int cin, int cout);
 void wino_set(int on);
 void wino_split_set(int on);
 void bf16_set_fast(int on);
+int launch_f32_to_bf16(const float* src, int ld_src, void* dst, int ld_dst, int col_off, long rows, int cols, hipStream_t s);
+int launch_linear_bf16(const void* a, const void* w, const float* bias, const float* res, const int64_t* res_idx,
+                       const float* res2, const int64_t* res2_idx, int ldr, float* out, int m, int k, int n_out, int relu,
+                       hipStream_t s);
 // Gathered residual rows added in the epilogue: out[m] += res1[idx1[m]] (+ res2[idx2[m]]), row pitch ld.
 struct GatherRes {
     const float* res1;

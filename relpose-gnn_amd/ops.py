@@ -108,6 +108,41 @@ def conv2d_bn_act_nhwc_bf16(x: torch.Tensor, w_ohwi: torch.Tensor, scale: Option
     return y
 
 
+def f32_to_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0) -> torch.Tensor:
+    """bf16 image of the fp32 matrix x [rows][cols] (written at column col_off of `out` when given)."""
+    x = _req(x, "x")
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device)
+    out = _req(out, "out", torch.bfloat16)
+    L.check(L.lib().rpg_f32_to_bf16(_p(x), cols, _p(out), out.shape[1], col_off, rows, cols, _stream()), "f32_to_bf16")
+    return out
+
+
+def linear_bf16(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                residual: Optional[torch.Tensor] = None, res_idx: Optional[torch.Tensor] = None,
+                residual2: Optional[torch.Tensor] = None, res2_idx: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    """out (fp32) = act(a (bf16) @ weight.T (bf16) + bias + residual[res_idx or arange] + residual2[res2_idx]); the
+    residual matrices are fp32 with a common row pitch."""
+    a, weight = _req(a, "a", torch.bfloat16), _req(weight, "weight", torch.bfloat16)
+    m, k = a.shape
+    n_out = weight.shape[0]
+    if weight.shape[1] != k:
+        raise ValueError("a.shape[1] != weight.shape[1]")
+    bias = None if bias is None else _req(bias, "bias")
+    residual = None if residual is None else _req(residual, "residual")
+    residual2 = None if residual2 is None else _req(residual2, "residual2")
+    res_idx = None if res_idx is None else _req(res_idx, "res_idx", torch.int64)
+    res2_idx = None if res2_idx is None else _req(res2_idx, "res2_idx", torch.int64)
+    if residual2 is not None and (residual is None or residual2.shape[1] != residual.shape[1]):
+        raise ValueError("residual2 needs residual with the same row pitch")
+    ldr = 0 if residual is None else residual.shape[1]
+    out = torch.empty((m, n_out), dtype=torch.float32, device=a.device)
+    L.check(L.lib().rpg_linear_bf16(_p(a), _p(weight), _p(bias), _p(residual), _p(res_idx), _p(residual2), _p(res2_idx), ldr,
+                                    _p(out), m, k, n_out, int(relu), _stream()), "linear_bf16")
+    return out
+
+
 def maxpool3x3s2_nhwc(x: torch.Tensor) -> torch.Tensor:
     x = _req(x, "x")
     n, h, w, c = x.shape

@@ -140,3 +140,12 @@ def pack_gnn(sd: Dict[str, torch.Tensor], gnn: str = "gnn1.") -> List[torch.Tens
         t.append(we[:, 2 * d:].contiguous())                                              # [D][D]
         t.append(wm[:, d:].contiguous())                                                  # [D][D]
     return t
+
+
+def pack_gnn_bf16(packed: List[torch.Tensor]) -> List[torch.Tensor]:
+    """bf16 images of the 10 GEMM weights of the split formulation, in the order rpg_gnn_forward_bf16 expects
+    (include/relpose_gnn_hip.h); `packed` is pack_gnn's 26-tensor table."""
+    if len(packed) != 26:
+        raise ValueError("the bf16 GNN needs the 26-tensor (node/edge split) table")
+    order = (22, 23, 24, 4, 25, 8, 10, 12, 14, 16)
+    return [packed[i].to(torch.bfloat16).contiguous() for i in order]

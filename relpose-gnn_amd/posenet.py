@@ -26,7 +26,7 @@ import torch.nn.functional as F
 
 from . import _lib as _L
 from . import ops
-from .params import pack_gnn
+from .params import pack_gnn, pack_gnn_bf16
 from .resnet import EncoderRunner
 
 
@@ -110,6 +110,9 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         self._enc = EncoderRunner()
         self._gnn_packed: Optional[List[torch.Tensor]] = None
         self._gnn_ptrs = None
+        self._gnn_bf16: Optional[List[torch.Tensor]] = None
+        self._gnn_bf16_ptrs = None
+        self._gnn_dtype = "f32"
         self._extra: Dict[str, torch.Tensor] = {}
         self._gnn_ws: Dict[Tuple, torch.Tensor] = {}
         self._checked_edges: Dict[Tuple, bool] = {}
@@ -123,11 +126,26 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
     def encoder_dtype(self, dtype: str) -> None:
         self._enc.set_dtype(dtype)
 
+    @property
+    def gnn_dtype(self) -> str:
+        """'f32' (default; the 1e-4 parity path) or 'bf16': the GNN's Linears on the bf16 matrix pipe (inputs rounded to
+        bf16 per Linear, fp32 accumulation / bias / residual / output; attention rows, scatter-mean and heads stay fp32).
+        Meant to go with encoder_dtype = 'bf16' (BASELINE configs[2]/[4]); needs the default flags (use_AP, no
+        use_attention, knn <= 0) and D % 64 == 0."""
+        return self._gnn_dtype
+
+    @gnn_dtype.setter
+    def gnn_dtype(self, dtype: str) -> None:
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("gnn_dtype must be 'f32' or 'bf16'")
+        self._gnn_dtype = dtype
+
     # ---- packed-weight cache ------------------------------------------------------------------------------------
     def refresh_packed(self) -> None:
         """Drop the packed device copies of the weights (call after mutating parameters in place)."""
         self._enc.invalidate()
         self._gnn_packed, self._gnn_ptrs = None, None
+        self._gnn_bf16, self._gnn_bf16_ptrs = None, None
         self._extra = {}
         self._gnn_ws.clear()
         self._checked_edges.clear()
@@ -171,6 +189,18 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
             ent = (key, raw[skew:])
             self._gnn_ws[slot] = ent
         ws = ent[1]
+        if self._gnn_dtype == "bf16":
+            if self._gnn_bf16 is None:
+                self._gnn_bf16 = pack_gnn_bf16(self._gnn_packed)
+                self._gnn_bf16_ptrs = _L.ptr_array([t.data_ptr() for t in self._gnn_bf16])
+            rc = lib.rpg_gnn_forward_bf16(self._gnn_ptrs, len(self._gnn_packed), self._gnn_bf16_ptrs, len(self._gnn_bf16),
+                                          feat.data_ptr(), esrc_ptr, edst_ptr, node_off, n, e, d, int(self.gnn_recursion),
+                                          abs_pose.data_ptr(), rel_pose.data_ptr(),
+                                          None if node_f is None else node_f.data_ptr(),
+                                          None if edge_f is None else edge_f.data_ptr(), status.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), torch.cuda.current_stream().cuda_stream)
+            _L.check(rc, "gnn_forward_bf16")
+            return
         rc = lib.rpg_gnn_forward_f32(self._gnn_ptrs, len(self._gnn_packed), feat.data_ptr(), esrc_ptr, edst_ptr, node_off, n,
                                      e, d, int(self.gnn_recursion), abs_pose.data_ptr(), rel_pose.data_ptr(),
                                      None if node_f is None else node_f.data_ptr(),

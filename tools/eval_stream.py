@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--shape", default="256x341")
     ap.add_argument("--micro-batch", type=int, default=32)
     ap.add_argument("--encoder-dtype", choices=("f32", "bf16"), default="f32")
+    ap.add_argument("--gnn-dtype", choices=("f32", "bf16"), default="f32")
     args = ap.parse_args()
     h, w = (int(v) for v in args.shape.split("x"))
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -50,6 +51,7 @@ def main():
     model.load_state_dict(S.synth_state_dict(S.posenet_r2_param_shapes(D, D, D), seed=1))
     model = model.to(dev).eval()
     model.encoder_dtype = args.encoder_dtype
+    model.gnn_dtype = args.gnn_dtype
 
     lo, hi = shard_range(args.graphs, rank, world)
     mb = args.micro_batch
@@ -109,7 +111,7 @@ def main():
         dt = float(t.item())
     if rank == 0:
         assert len(poses) == args.graphs
-        print(json.dumps({"workload": f"eval-shape stream: {args.graphs} 8-node FC graphs, {h}x{w}, encoder {args.encoder_dtype}, "
+        print(json.dumps({"workload": f"eval-shape stream: {args.graphs} 8-node FC graphs, {h}x{w}, encoder {args.encoder_dtype}, GNN Linears {args.gnn_dtype}, "
                                       f"micro-batch {mb}, pipelined D2H + test.py post-processing per graph included",
                           "n_gpus": world, "graphs": args.graphs, "seconds": round(dt, 3),
                           "graphs_per_s": round(args.graphs / dt, 1)}), flush=True)
