@@ -53,6 +53,61 @@ def test_random_conv_direct(dev, case):
     assert rel_err(y.cpu().permute(0, 3, 1, 2), ref) < 1e-5, (kh, kw, stride, pad, cin, cout, n, h, w)
 
 
+@pytest.mark.parametrize("case", range(24))
+def test_random_conv_buffer_loaders(dev, case):
+    """Shapes that take the buffer-load loaders of the tile engine: Cin a multiple of 16 / 32 (ConvLoaderB) or Cin = 4 with
+    a >= 4-wide kernel (ConvLoaderTap), random kernel / stride / padding / image sizes (many images per tile, rows that
+    start in the padding, K tails for the tap loader)."""
+    from relpose_gnn_amd import ops
+    rng = random.Random(5000 + case)
+    if case % 3 == 2:
+        cin, kh, kw = 4, rng.choice([3, 5, 7]), rng.choice([4, 5, 7])
+    else:
+        cin, kh, kw = rng.choice([16, 32, 48, 64, 96, 128]), rng.choice([1, 2, 3]), rng.choice([1, 2, 3])
+    stride, pad = rng.choice([1, 2, 3]), rng.choice([0, 1, 2, 3])
+    cout = rng.choice([4, 32, 60, 64, 100, 128, 200])
+    n, h, w = rng.randint(1, 9), rng.randint(max(kh - 2 * pad, 1), 30), rng.randint(max(kw - 2 * pad, 1), 30)
+    res, relu = rng.random() < 0.5, rng.random() < 0.5
+    x = _rand(n, cin, h, w, seed=case)
+    wt = _rand(cout, cin, kh, kw, seed=case + 1, scale=(1.0 / (cin * kh * kw)) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(case + 2)) + 0.5
+    shift = _rand(cout, seed=case + 3, scale=0.2)
+    ref = F.conv2d(x, wt, None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    r = None
+    if res:
+        r = _rand(*ref.shape, seed=case + 4)
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    y = ops.conv2d_bn_act_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev),
+                               scale.to(dev), shift.to(dev), None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev),
+                               stride=stride, pad=pad, relu=relu)
+    assert rel_err(y.cpu().permute(0, 3, 1, 2), ref) < 1e-5, (kh, kw, stride, pad, cin, cout, n, h, w)
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_linear_aligned(dev, case):
+    """Ungathered sources whose widths are multiples of 32: GatherLoaderB + the interleaved main loop (all tile shapes
+    the size heuristics pick, stream-K included)."""
+    from relpose_gnn_amd import ops
+    rng = random.Random(6000 + case)
+    ns = rng.randint(1, 3)
+    widths = [32 * rng.randint(1, 20) for _ in range(ns)]
+    m, n_out = rng.randint(1, 2000), 4 * rng.randint(1, 600)
+    srcs = [(_rand(m, wd, seed=case * 5 + i).to(dev), None) for i, wd in enumerate(widths)]
+    k = sum(widths)
+    wl, bias = _rand(n_out, k, seed=case + 60, scale=k ** -0.5), _rand(n_out, seed=case + 61)
+    res = _rand(m, n_out, seed=case + 62) if rng.random() < 0.5 else None
+    relu = rng.random() < 0.5
+    ref = F.linear(torch.cat([a.cpu() for a, _ in srcs], 1), wl, bias)
+    if res is not None:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    y = ops.linear_gather(srcs, wl.to(dev), bias.to(dev), m, None if res is None else res.to(dev), relu)
+    assert rel_err(y.cpu(), ref) < 1e-5, (widths, m, n_out)
+
+
 @pytest.mark.parametrize("kernel", [2, 3], ids=["wave4", "wave8"])
 @pytest.mark.parametrize("case", range(16))
 def test_random_conv_winograd(dev, case, kernel):
