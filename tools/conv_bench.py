@@ -18,6 +18,11 @@ SHAPES = [  # name, n, h, w, cin, cout, k, stride, pad, residual
     ("l2.c1", 256, 28, 28, 128, 128, 3, 1, 1, False),
     ("l2.c2", 256, 28, 28, 128, 128, 3, 1, 1, True),
     ("l2.ds", 256, 56, 56, 64, 128, 1, 2, 0, False),
+    ("l2.s2", 256, 56, 56, 64, 128, 3, 2, 1, False),
+    ("l3.s2", 256, 28, 28, 128, 256, 3, 2, 1, False),
+    ("l3.ds", 256, 28, 28, 128, 256, 1, 2, 0, False),
+    ("l4.s2", 256, 14, 14, 256, 512, 3, 2, 1, False),
+    ("l4.ds", 256, 14, 14, 256, 512, 1, 2, 0, False),
     ("l3.c1", 256, 14, 14, 256, 256, 3, 1, 1, False),
     ("l3.c2", 256, 14, 14, 256, 256, 3, 1, 1, True),
     ("l4.c1", 256, 7, 7, 512, 512, 3, 1, 1, False),
