@@ -634,15 +634,16 @@ bool wino_enabled() { return g_wino != 0; }
 void wino_set(int on) { g_wino = on; }
 void wino_split_set(int on) { g_wino_split = on; }
 
-// Winograd needs (a) 32-bit buffer offsets (checked again by the launcher) and (b) enough 64-tile x 64-channel units
-// of work to occupy the chip: its K loop is not split, so a small grid is latency-bound (measured crossover vs the
-// direct kernel with stream-K: ~128 workgroups = half the CUs; e.g. 8 images: layer3 117 us vs 47 us, layer4 216 vs 63).
+// Winograd needs (a) 32-bit buffer offsets (checked again by the launcher) and (b) enough work to occupy the chip.  Since
+// the 8-wave kernel cuts a grid that does not fill the CUs along K (split-K tail), that is little: from 16 units of 64
+// tiles x 64 channels on it beats the direct kernel + stream-K (measured on the whole forward: 2 graphs 1068 -> 1198
+// graphs/s, 4: 1400 -> 1525, 8: 1891 -> 2149; 1 graph: equal).
 bool wino_pays(int n, int h, int w, int cin, int cout) {
     if (!g_wino || (cin & 3) || (cout & 3)) return false;
     const long tiles = (long)n * h * ((w + 3) / 4);
     const long blocks = ((tiles + BMT - 1) / BMT) * ((cout + BN - 1) / BN);
     const int tw = (w + 3) / 4;
-    return blocks >= 128 && (long)h * w * cin * 4 * 67 < (1L << 31) && 6L * cout * 3 * cin * 4 < (1L << 31) &&
+    return blocks >= 16 && (long)h * w * cin * 4 * 67 < (1L << 31) && 6L * cout * 3 * cin * 4 < (1L << 31) &&
            (32L / tw + 3) * w * cout * 4 < (1L << 31);
 }
 
@@ -671,7 +672,7 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
     const int slot = timing_begin(RPG_TIMER_CONV_WINO, s);
     const long tm8 = (M + BMT8 - 1) / BMT8;
     const bool fits8 = (long)h * w * cin * 4 * 131 < (1L << 31);     // a workgroup's 128 tiles span at most 129 images
-    if (fits8 && (g_wino == 3 || (g_wino == 1 && tm8 * tn >= 64))) {
+    if (fits8 && (g_wino == 3 || (g_wino == 1 && tm8 * tn >= 8))) {
         // large problems (or RPG_TUNE_WINOGRAD = 3): 8 waves on 128 tiles, double-buffered, one workgroup per CU.
         // The tiles beyond the last full round of CUs would cost a whole extra round (784 tiles on 256 CUs: a 4th
         // round for 2 % of the work): they are cut along K into floor(CUs / tail) parts (>= 4 K steps each) whose partial
