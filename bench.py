@@ -11,9 +11,13 @@ gnn_recursion=2, droprate=0, eval) over one batch of 32 graphs (256 images) per 
 with the inputs already resident in HBM; for N>1 each rank runs its own batch (weak scaling, graphs are independent)
 and the predicted relative poses are all-gathered over RCCL every step.  Rank 0 prints ONE JSON line.
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself (a child
+`python -m torch.distributed.run`, spawned before this process touches the GPU) and relays their JSON line.
+
 The line also carries
-  roofline     for the dominant kernel (the implicit-GEMM f32-MFMA convolution): algorithmic FLOP of all its launches
-               in the timed steps / their summed HIP-event durations, against the 157.3 TFLOP/s f32 matrix peak;
+  roofline     for the dominant kernel (the Winograd F(4,3) f32-MFMA convolution): the FLOP its launches EXECUTE on the
+               matrix pipe / their summed HIP-event durations, against the 157.3 TFLOP/s f32 matrix peak (frac <= 1); the
+               algorithmic (direct-convolution) rate and the algorithmic / executed ratio are separate fields;
   cpu_baseline the CPU oracle (validated against the reference in this repo's build container) timed on this box's
                host cores on a bounded sample of the same workload (N=1 only).
 """
@@ -105,10 +109,36 @@ def cpu_baseline(budget_s: float):
                       f"(32 images 224x224 each), torch {torch.__version__} CPU fp32, {secs:.1f} s"}
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: run the N ranks as a child `torch.distributed.run` (this process has
+    not initialised the GPU: nothing before this point calls into HIP) and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.lstrip().startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc else (0 if line is not None else 1)
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-worker":
         return cpu_worker(float(sys.argv[2]), int(sys.argv[3]))
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     cpu_line = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.cpu_baseline_seconds > 0:
         cpu_line = cpu_baseline(args.cpu_baseline_seconds)      # child processes, before any GPU initialisation here
@@ -116,8 +146,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP kernels are the only compute path)")
     torch.cuda.set_device(local_rank)
@@ -196,6 +225,28 @@ def main():
     model.encoder_dtype = args.encoder_dtype
     if args.bf16_bk:
         ops.set_tuning(ops.TUNE_BF16_BK, args.bf16_bk)
+    # the scatter-mean kernel on its own at an HBM-sized launch (2048 graphs: 1.07 GB algorithmic, past L2 + MALL)
+    scatter_iso = None
+    if kt is not None and rank == 0 and args.encoder_dtype == "f32":
+        gi = 2048
+        big = fc_batch(torch.empty((NODES * gi, 1), device=dev), NODES)
+        gp = ops.graph_prepare(big.edge_index, NODES * gi)
+        msg = torch.randn((NODES * (NODES - 1) * gi, D), device=dev)
+        for _ in range(2):
+            ops.scatter_mean(msg, gp["rowptr"], gp["perm"], NODES * gi)
+        ops.timing_read()
+        ops.timing_enable(True)
+        for _ in range(10):
+            ops.scatter_mean(msg, gp["rowptr"], gp["perm"], NODES * gi)
+        ops.timing_enable(False)
+        v = ops.timing_read()["scatter"]
+        gbs = v["work"] / (v["ms"] * 1e-3) / 1e9
+        scatter_iso = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(gbs / HBM_PEAK_GBS, 4), "launches": v["launches"],
+                       "avg_launch_ms": round(v["ms"] / v["launches"], 5),
+                       "what": f"the same kernel alone at {gi} graphs per launch ({round(v['work'] / v['launches'] / 1e6)} MB "
+                               "algorithmic, back-to-back launches on one stream)"}
+        del msg, gp, big
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -215,7 +266,8 @@ def main():
                                    "fp32, ResNet34 + GNN (D=2048, gnn_recursion=2, droprate=0, eval), random-init weights",
                        "graphs_per_step_per_gpu": B, "nodes_per_graph": NODES, "edges_per_graph": NODES * (NODES - 1),
                        "image": [IMG, IMG], "streams_per_gpu": args.streams,
-                       "parallelism": f"graph-sharded x{world}, all-gather of rel poses per step"},
+                       "parallelism": f"graph-sharded x{world}: one process per GPU, RCCL world_size={world}, weights replicated, "
+                                      "one all-gather of the rel poses per step (no other collective)"},
         }
         if kt is not None and args.encoder_dtype == "bf16" and kt["conv"]["launches"]:
             c = kt["conv"]
@@ -233,37 +285,48 @@ def main():
                                                     "launches": v["launches"], "avg_launch_ms": round(v["ms"] / v["launches"], 5)}}
         elif kt is not None and kt["conv_wino"]["launches"]:
             c = kt["conv_wino"]
-            ach = c["work"] / (c["ms"] * 1e-3) / 1e12
-            traffic, traffic_src, pmc = None, None, {}
-            tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic_wino43.json")
-            if os.path.exists(tpath):          # PMC counters cannot be read from inside the process: committed profile
-                with open(tpath) as f:
-                    tj = json.load(f)
-                traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/r1_pmc_traffic_wino43.json (rocprofv3 --pmc, corrected)"
-                pmc = {k: tj[k] for k in ("executed_mfma_gflop_per_launch", "mfma_busy_frac", "cu_busy_frac", "shader_clock_ghz") if k in tj}
+            avg_ms = c["ms"] / c["launches"]
+            alg = c["work"] / (c["ms"] * 1e-3) / 1e12            # direct-convolution FLOP / time
+            exe = c["executed"] / (c["ms"] * 1e-3) / 1e12        # FLOP the matrix pipe issues / time
             line["roofline"] = {
-                "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "bound": "mfma", "achieved": round(exe, 2), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(exe / F32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                "what": "achieved = EXECUTED matrix-pipe FLOP of the launches (workgroups x K steps x 48 MFMAs x 8 waves x 4096, "
+                        "counted by the launcher; equals SQ_INSTS_VALU_MFMA_F32 x 4096 of the PMC profile) / their summed "
+                        "HIP-event durations",
                 "kernel": "wino43_conv8_kernel (3x3/stride-1 conv + BN (+residual) + ReLU as 1-D Winograd F(4,3) on "
                           "v_mfma_f32_32x32x2_f32; 29 of the 36 ResNet34 convolutions); a launch = the <false> main kernel "
                           "plus, on layers with a tail, its split-K <true> kernel and wino43_fixup_kernel",
-                "launches": c["launches"], "avg_launch_ms": round(c["ms"] / c["launches"], 4),
-                "alg_gflop_per_launch": round(c["work"] / c["launches"] / 1e9, 3),
-                "note": "achieved = ALGORITHMIC (direct-convolution) FLOP / duration; F(4,3) executes ~0.5-0.57x of them "
-                        "on the matrix pipe, so frac can exceed 1; the pipe's own occupancy is pmc.mfma_busy_frac "
-                        "(SQ_VALU_MFMA_BUSY_CYCLES, see DESIGN.md)",
-                "pmc": pmc,
-                "executed": (None if "executed_mfma_gflop_per_launch" not in pmc else {
-                    "tflops": round(pmc["executed_mfma_gflop_per_launch"] / (c["ms"] / c["launches"]), 2),
-                    "frac_of_peak": round(pmc["executed_mfma_gflop_per_launch"] / (c["ms"] / c["launches"]) / F32_MATRIX_PEAK_TFLOPS, 4),
-                    "what": "FLOP the matrix pipe really executes per launch (SQ_INSTS_VALU_MFMA_F32 x 4096, committed PMC "
-                            "profile) / this run's average launch duration"}),
+                "launches": c["launches"], "avg_launch_ms": round(avg_ms, 4),
+                "executed_gflop_per_launch": round(c["executed"] / c["launches"] / 1e9, 3),
+                "algorithmic": {"gflop_per_launch": round(c["work"] / c["launches"] / 1e9, 3), "tflops": round(alg, 2),
+                                "over_executed": round(c["work"] / c["executed"], 4),
+                                "note": "SURVEY 8(d) counts the direct convolution (2*9*Cin MACs per output); F(4,3) issues "
+                                        "about half of them, so the algorithmic rate may exceed the matrix peak"},
                 "share_of_instrumented_step_time": round(c["ms"] / (1e3 * elapsed_ev), 4),
                 "measured_on": f"{args.steps} further steps of the same workload, one stream, per-launch HIP events: "
                                f"{round(1e3 * elapsed_ev / args.steps, 3)} ms/step, vs "
                                f"{round(1e3 * elapsed / args.steps, 3)} ms/step in the timed region "
                                f"({args.streams} concurrent streams, no events)",
             }
+            # PMC counters cannot be read from inside the process: they come from a COMMITTED rocprofv3 --pmc profile of
+            # this command, used only if it was taken at this batch size, and labelled with the kernel sources it saw
+            from relpose_gnn_amd.build import source_digest
+            tpath = os.path.join(ROOT, "profiles", "r2_pmc_wino43.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get("graphs_per_step") == B:
+                    same = tj.get("source_digest") == source_digest()
+                    line["roofline"]["traffic"] = round(tj["traffic_bytes_per_launch"])
+                    line["roofline"]["committed_profile"] = {
+                        "file": "profiles/r2_pmc_wino43.json", "source_digest": tj.get("source_digest"),
+                        "git_commit": tj.get("git_commit"), "matches_running_kernels": same,
+                        "graphs_per_step": tj.get("graphs_per_step"),
+                        "what": "traffic = 1024 * (2 * FETCH_SIZE + WRITE_SIZE) per launch of the main kernel, separate "
+                                "--pmc passes, read side doubled per MI355X_MICROARCH.md; NOT observed in this run",
+                        **{k: tj[k] for k in ("algorithmic_bytes_per_launch", "traffic_over_algorithmic", "mfma_busy_frac",
+                                              "cu_busy_frac", "shader_clock_ghz", "executed_mfma_gflop_per_launch") if k in tj}}
             other = {}
             for k in ("conv", "linear", "attention", "scatter"):
                 v = kt[k]
@@ -273,13 +336,18 @@ def main():
                     gbs = v["work"] / (v["ms"] * 1e-3) / 1e9
                     other[k] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(gbs / HBM_PEAK_GBS, 4), "launches": v["launches"],
-                                "avg_launch_ms": round(v["ms"] / v["launches"], 5)}
-                else:
-                    tf = v["work"] / (v["ms"] * 1e-3) / 1e12
-                    other[k] = {"achieved": round(tf, 2), "unit": "TFLOP/s", "launches": v["launches"],
                                 "avg_launch_ms": round(v["ms"] / v["launches"], 5),
+                                "what": "in-pipeline launches (524,736 algorithmic bytes per graph per launch)"}
+                else:
+                    tf = v["executed"] / (v["ms"] * 1e-3) / 1e12
+                    other[k] = {"achieved": round(tf, 2), "unit": "TFLOP/s", "frac": round(tf / F32_MATRIX_PEAK_TFLOPS, 4),
+                                "algorithmic_tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                "launches": v["launches"], "avg_launch_ms": round(v["ms"] / v["launches"], 5),
                                 "share_of_instrumented_step_time": round(v["ms"] / (1e3 * elapsed_ev), 4)}
-            other["conv"]["kernel"] = "direct implicit-GEMM conv (stem 7x7/2, three 3x3/2, three 1x1/2)"
+            if "conv" in other:
+                other["conv"]["kernel"] = "direct implicit-GEMM conv (stem 7x7/2, three 3x3/2, three 1x1/2)"
+            if scatter_iso is not None:
+                other["scatter_isolated"] = scatter_iso
             line["other_kernels"] = other
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line

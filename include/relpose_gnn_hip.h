@@ -10,8 +10,15 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer to caller-owned, 16-byte aligned memory (except where
- *     marked HOST); nothing is allocated inside a call; no call synchronises the device
- *     (except rpg_timing_read);
+ *     marked HOST); no call synchronises the device (except rpg_timing_read* and
+ *     rpg_release_scratch);
+ *   - the composite forwards (rpg_resnet_forward_*, rpg_gnn_forward_*) allocate nothing: all their
+ *     memory, including the partial-tile scratch of the split-K / stream-K launches, is the
+ *     caller's workspace (rpg_*_workspace_bytes), so they can be captured into a HIP graph as is.
+ *     The fine-grained convolution / Linear entry points have no workspace argument: when a shape
+ *     calls for a split-K pass they use a library-owned scratch block per (device, stream) that
+ *     only grows (old blocks stay valid; never grown while the stream is being captured -- the
+ *     launch then simply does not split); rpg_release_scratch() frees the pool;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
  *   - tensors are dense fp32, indices are int64 (the dtype of PyG's edge_index);
  *   - return value: 0 = RPG_OK, negative = error, never throws across the ABI.
@@ -37,6 +44,8 @@ extern "C" {
 int rpg_abi_version(void);
 /* HOST: static string describing the last RPG_ERR_LAUNCH on this thread ("" if none). */
 const char* rpg_last_error(void);
+/* Synchronises the device and frees the library-owned split-K scratch pool (see conventions). */
+int rpg_release_scratch(void);
 
 /* ------------------------------------------------------------------------------------------- */
 /* Encoder primitives (replace aten conv2d + batch_norm + relu + max_pool2d + adaptive_avg_pool */
@@ -110,9 +119,10 @@ int rpg_resnet_forward_bf16(const void* const* tensors, int n_tensors, const int
  *   rowptr [n+1], perm [e]   CSR of edges grouped by TARGET node, edge ids ascending inside a
  *                  group (the order torch_scatter's CPU kernel accumulates in)
  *   cursor [n]     scratch
- *   status [1]     number of edges with an endpoint outside [0, n) (0 = valid); such edges are
- *                  left out of the CSR and their endpoints clamped, so no later kernel reads out
- *                  of bounds.  The host mirror raises IndexError when it is non-zero.
+ *   status [1]     += number of edges with an endpoint outside [0, n) (the caller zeroes it; a
+ *                  counter that several calls share accumulates); such edges are left out of the
+ *                  CSR and their endpoints clamped, so no later kernel reads out of bounds.  The
+ *                  host mirror raises IndexError when it reads a non-zero count back.
  * Single workgroup; e and n up to 2^20.                                                          */
 int rpg_graph_prepare(const int64_t* src, const int64_t* dst, int64_t node_offset, int e, int n, int64_t* ends,
                       int32_t* rowptr, int32_t* cursor, int32_t* perm, int32_t* status, void* stream);
@@ -206,13 +216,17 @@ int rpg_timing_enable(int enable);
  * HOST outputs, arrays of RPG_TIMER_COUNT: total milliseconds, launches, algorithmic work
  * (FLOP for CONV/LINEAR/ATTENTION, bytes for SCATTER).                                          */
 int rpg_timing_read(double* ms, long long* launches, double* work);
+/* The same plus executed[k]: the FLOP the matrix pipe really issues for those launches (whole padded
+ * tiles; for the Winograd kernels workgroups x K steps x 48 MFMAs x waves x 4096, i.e. about half of
+ * the algorithmic direct-convolution FLOP).  executed may be NULL.                               */
+int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* executed);
 
 /* Tuning knobs of the f32 MFMA tile engine (benchmarking aid; defaults are the tuned choice).
  *   RPG_TUNE_TILE      -1 automatic (default) | 0: 128x128 | 1: 256x64 | 2: 64x64 | 3: 128x64 workgroup tile
  *   RPG_TUNE_BK        K-step: 0 automatic (default: 32 for the 128x128 tile, else 16) | 16 | 32
  *   RPG_TUNE_EPILOGUE  1: LDS-transposed 16-byte epilogue (default) | 0: direct 4-byte epilogue
  *   RPG_TUNE_STREAMK   1: stream-K pass for the tiles that do not fill a round of resident workgroups
- *                      (default; uses a library-owned per-stream scratch buffer, grown on demand) | 0: off  */
+ *                      (default; partial tiles go to the caller's workspace / the scratch pool) | 0: off  */
 #define RPG_TUNE_TILE 0
 #define RPG_TUNE_BK 1
 #define RPG_TUNE_EPILOGUE 2

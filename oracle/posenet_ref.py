@@ -201,14 +201,22 @@ def knn_graph(x: Tensor, k: int, batch: Optional[Tensor] = None) -> Tensor:
 
 
 def gnn_forward(sd: Dict[str, Tensor], x: Tensor, edge_index: Tensor, gnn_recursion: int = 2,
-                stages: Optional[Dict[str, Tensor]] = None, use_AP: bool = True) -> Tuple[Tensor, Tensor]:
-    """Everything after the encoder: posenet.py:1052-1091 with use_gnn, droprate=0 (edge_index already final)."""
+                stages: Optional[Dict[str, Tensor]] = None, use_AP: bool = True, node_mask: Optional[Tensor] = None,
+                edge_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """Everything after the encoder: posenet.py:1052-1091 with use_gnn (edge_index already final).  The reference's
+    always-on dropout (posenet.py:1073-1075, F.dropout without training=) is stated with EXPLICIT masks: node_mask [N,D] /
+    edge_mask [E,D] hold 0 for a dropped element and 1/(1-p) for a kept one, exactly what F.dropout multiplies by; None =
+    droprate 0.  (The random draw itself cannot be pinned across devices; the arithmetic around it can.)"""
     e = F.relu(F.linear(edge_concat(x, edge_index), sd["proj_edge.weight"], sd["proj_edge.bias"]))
     if stages is not None:
         stages["proj_edge"] = e
     for r in range(gnn_recursion):          # same gnn1 weights every recursion (:1061-1069)
         x, e = gnn_layer(sd, "gnn1.", x, edge_index, e, stages, f"r{r}.")
         x, e = F.relu(x), F.relu(e)
+    if node_mask is not None:                                          # posenet.py:1073-1075
+        x = x * node_mask
+    if edge_mask is not None:
+        e = e * edge_mask
     h = x if use_AP else edge_concat(x, edge_index)                    # posenet.py:1077-1083
     abs_pose = torch.cat([F.linear(h, sd["fc_xyz.weight"], sd["fc_xyz.bias"]),
                           F.linear(h, sd["fc_wpqr.weight"], sd["fc_wpqr.bias"])], dim=1)
@@ -220,7 +228,8 @@ def gnn_forward(sd: Dict[str, Tensor], x: Tensor, edge_index: Tensor, gnn_recurs
 @torch.no_grad()
 def posenet_forward(sd: Dict[str, Tensor], x_flat: Tensor, edge_index: Tensor, img_h: int,
                     gnn_recursion: int = 2, stages: Optional[Dict[str, Tensor]] = None, use_attention: bool = False,
-                    use_AP: bool = True, knn: int = -1, k: Optional[int] = None, batch: Optional[Tensor] = None
+                    use_AP: bool = True, knn: int = -1, k: Optional[int] = None, batch: Optional[Tensor] = None,
+                    node_mask: Optional[Tensor] = None, edge_mask: Optional[Tensor] = None
                     ) -> Tuple[Tensor, Tensor, Tensor]:
     """data.x [N,3*H*W], data.edge_index [2,E] -> (abs, rel[E,6], edge_index) -- posenet.py:1033-1091, droprate=0."""
     x = x_flat.view(x_flat.shape[0], 3, img_h, -1).contiguous()       # posenet.py:1035
@@ -232,7 +241,7 @@ def posenet_forward(sd: Dict[str, Tensor], x_flat: Tensor, edge_index: Tensor, i
         edge_index = knn_graph(feat, knn, batch)
     elif k is not None:
         edge_index = knn_graph(feat, k, batch)
-    abs_pose, rel_pose = gnn_forward(sd, feat, edge_index, gnn_recursion, stages, use_AP)
+    abs_pose, rel_pose = gnn_forward(sd, feat, edge_index, gnn_recursion, stages, use_AP, node_mask, edge_mask)
     return abs_pose, rel_pose, (edge_index_knn if k is not None else edge_index)   # :1088-1091
 
 

@@ -24,6 +24,7 @@ SYMBOLS = (
     "rpg_gnn_forward_f32", "rpg_timing_enable", "rpg_timing_read", "rpg_set_tuning", "rpg_knn_graph_f32", "rpg_wino43_transform_weights_f32",
     "rpg_conv3x3_wino43_bn_act_nhwc_f32", "rpg_conv2d_bn_act_nhwc_bf16", "rpg_resnet_bf16_workspace_bytes",
     "rpg_resnet_forward_bf16", "rpg_gnn_forward_bf16", "rpg_f32_to_bf16", "rpg_linear_bf16",
+    "rpg_release_scratch", "rpg_timing_read_ex",
 )
 
 
@@ -76,6 +77,9 @@ def _declare(lib: C.CDLL) -> None:
     lib.rpg_conv3x3_wino43_bn_act_nhwc_f32.argtypes = [_vp] * 6 + [_i] * 6 + [_vp]
     lib.rpg_knn_graph_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.rpg_timing_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
+    lib.rpg_timing_read_ex.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double)]
+    lib.rpg_release_scratch.argtypes = []
     for name in SYMBOLS:
         getattr(lib, name)          # AttributeError here = the library does not export a declared symbol
 

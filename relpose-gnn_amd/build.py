@@ -27,6 +27,20 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+def source_digest() -> str:
+    """12 hex digits identifying the kernel sources (csrc/* + the C header): profiles/ artefacts are stamped with it so
+    that bench.py can tell whether a committed PMC profile was measured on the kernels it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [
+        os.path.join(os.path.dirname(HERE), "include", "relpose_gnn_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True

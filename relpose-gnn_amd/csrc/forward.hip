@@ -49,7 +49,7 @@ ResnetPlan plan_resnet(int n, int h, int w, const int* planes) {
     p.blk = blk;
     p.pool = (size_t)n * planes[3];
     p.total_bytes = align_up(p.in4 * 4, 256) + align_up(p.stem * 4, 256) + 4 * align_up(p.blk * 4, 256) +
-                    align_up(p.pool * 4, 256) + 7 * rpg::kWorkspaceSkew;
+                    align_up(p.pool * 4, 256) + align_up(rpg::split_scratch_bytes(), 256) + 8 * rpg::kWorkspaceSkew;
     return p;
 }
 
@@ -86,6 +86,8 @@ extern "C" int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors
     float* buf[4];
     for (int i = 0; i < 4; ++i) buf[i] = cv.take<float>(p.blk);
     float* pool = cv.take<float>(p.pool);
+    const size_t scratch_bytes = rpg::split_scratch_bytes();
+    rpg::ScratchScope scratch(cv.take<char>(scratch_bytes), scratch_bytes);     // split-K partial tiles of this call
 
     int rc;
     int ti = 0;
@@ -179,6 +181,7 @@ size_t gnn_bytes(int n, int e, int d) {
     add((size_t)n * d * 4, 4);              // agg, node hidden, x ping-pong
     add((size_t)n * 3 * d * 4);             // per-node partial products of the split Linears
     add((size_t)(e > 2 * n ? e : 2 * n) * d * 2);   // bf16 image of a Linear's input (bf16 GNN only)
+    add(rpg::split_scratch_bytes());                // stream-K partial tiles
     return b;
 }
 }  // namespace
@@ -225,6 +228,8 @@ int gnn_forward_impl(const float* const* tensors, int n_tensors, const void* con
     float* xbuf[2] = {cv.take<float>((size_t)n * d), cv.take<float>((size_t)n * d)};
     float* node3 = cv.take<float>((size_t)n * 3 * d);
     void* abf = cv.take<unsigned short>((size_t)(e > 2 * n ? e : 2 * n) * d);
+    const size_t scratch_bytes = rpg::split_scratch_bytes();
+    rpg::ScratchScope scratch(cv.take<char>(scratch_bytes), scratch_bytes);
 
     int rc;
     if ((rc = rpg_graph_prepare(esrc, edst, node_offset, e, n, ends, rowptr, cursor, perm, status, stream)) != RPG_OK) return rc;

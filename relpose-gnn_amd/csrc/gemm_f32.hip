@@ -22,8 +22,11 @@
 // Tiles: 128x128, 256x64 (Cout = 64), 128x64 and 64x64 (small problems); a stream-K pass + fix-up kernel balances the
 // tiles that do not fill a round of resident workgroups.  Workgroup ids are remapped so that the tiles sharing an A
 // row-panel run on one XCD (shared L2).
+#include <atomic>
 #include <map>
 #include <mutex>
+#include <utility>
+#include <vector>
 
 #include "rpg_common.h"
 
@@ -807,31 +810,47 @@ int g_gnn_split = 1;
 constexpr int SK_MIN_ITS = 8;        // at least this many k-steps per stream-K workgroup
 constexpr int SK_MIN_NK = 32;        // tiles with fewer k-steps are not worth splitting (fix-up traffic dominates)
 
-// Per-stream scratch for stream-K partial tiles (grown on demand; growth synchronises the device once).
+// Library-owned scratch pool of the fine-grained entry points (see rpg_common.h): one block per (device, stream) that
+// only grows; a grown block's predecessor is retired, not freed (a captured HIP graph or work still in flight may
+// hold its address), and nothing is allocated while the stream is being captured.
 struct Scratch { float* p = nullptr; size_t bytes = 0; };
 std::mutex g_scratch_mu;
-std::map<hipStream_t, Scratch> g_scratch;
+std::map<std::pair<int, hipStream_t>, Scratch> g_scratch;
+std::vector<float*> g_retired;
+struct ScratchTls { float* p = nullptr; size_t bytes = 0; bool on = false; };
+thread_local ScratchTls t_scratch;
+
 float* get_scratch(hipStream_t s, size_t bytes) {
+    if (t_scratch.on) return bytes <= t_scratch.bytes ? t_scratch.p : nullptr;     // caller workspace (composite forwards)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    Scratch& sc = g_scratch[s];
+    Scratch& sc = g_scratch[{dev, s}];
     if (sc.bytes < bytes) {
-        if (sc.p) (void)hipFree(sc.p);
-        sc.p = nullptr; sc.bytes = 0;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (cap != hipStreamCaptureStatusNone) return nullptr;                      // no allocation inside a capture
+        float* np = nullptr;
         const size_t want = bytes + bytes / 4;
-        if (hipMalloc(reinterpret_cast<void**>(&sc.p), want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMalloc(reinterpret_cast<void**>(&np), want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (sc.p) g_retired.push_back(sc.p);
+        sc.p = np;
         sc.bytes = want;
     }
     return sc.p;
 }
 
+constexpr int MAX_DEV = 64;
 int cu_count() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
+    static std::atomic<int> n[MAX_DEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
+    int v = n[dev].load(std::memory_order_relaxed);
+    if (!v) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n[dev].store(v, std::memory_order_relaxed);
     }
-    return n;
+    return v;
 }
 
 inline TileShape pick_tile(int M, int N, int K) {
@@ -846,6 +865,8 @@ inline TileShape pick_tile(int M, int N, int K) {
     return TILE_64x64;
 }
 
+thread_local double t_executed = 0.0;      // FLOP the matrix pipe issues for the last launch_one (whole padded tiles)
+
 template <int BM, int BN, int WM, int WN, int BK, bool EPI, template <int, int> class Loader, class Args>
 int launch_one(const Args& args, const float* Wt, int ldw, int M, int N, int K, const Epilogue& ep, bool vec_ok,
                hipStream_t s) {
@@ -853,7 +874,10 @@ int launch_one(const Args& args, const float* Wt, int ldw, int M, int N, int K, 
     auto kern = gemm_tile_kernel<BM, BN, WM, WN, BK, EPI, Loader, Args>;
     auto kern_sk = gemm_streamk_kernel<BM, BN, WM, WN, BK, EPI, Loader, Args>;
     constexpr int lds = T::LDS_BYTES;
-    static int occ = 0;               // resident workgroups per CU of this instantiation
+    static std::atomic<int> occ_dev[MAX_DEV];          // resident workgroups per CU of this instantiation, per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
+    int occ = occ_dev[dev].load(std::memory_order_relaxed);
     if (!occ) {
         if (lds > 64 * 1024) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -865,10 +889,12 @@ int launch_one(const Args& args, const float* Wt, int ldw, int M, int N, int K, 
         occ = o1 < o2 ? o1 : o2;
         if (occ < 1) occ = 1;
         (void)hipGetLastError();
+        occ_dev[dev].store(occ, std::memory_order_relaxed);
     }
     const int tn = (N + BN - 1) / BN, tm = (M + BM - 1) / BM;
     const int tiles = tm * tn, nk = (K + BK - 1) / BK;
     const int slots = cu_count() * occ;
+    t_executed = 2.0 * (double)tiles * BM * BN * (double)nk * BK;
     int t_dp = tiles, its_per = 0, g_sk = 0;
     float* partial = nullptr;
     if (g_streamk && nk >= SK_MIN_NK && tiles % slots != 0) {
@@ -947,6 +973,13 @@ namespace rpg {
 
 bool gnn_split_enabled() { return g_gnn_split != 0; }
 float* stream_scratch(hipStream_t s, size_t bytes) { return get_scratch(s, bytes); }
+ScratchScope::ScratchScope(void* p, size_t bytes) {
+    t_scratch.p = static_cast<float*>(p);
+    t_scratch.bytes = bytes;
+    t_scratch.on = true;
+}
+ScratchScope::~ScratchScope() { t_scratch = ScratchTls{}; }
+size_t split_scratch_bytes() { return (size_t)2 * 3 * cu_count() * 65536; }
 int num_cus() { return cu_count(); }
 
 int launch_conv(const float* x, const float* w, const float* scale, const float* shift, const float* residual,
@@ -969,7 +1002,7 @@ int launch_conv(const float* x, const float* w, const float* scale, const float*
     int seg = span * h * wd * cin * 4 >= (1L << 31) ? 0 : (cin % 32 == 0 ? 32 : (cin % 16 == 0 ? 16 : 0));
     if (cin == 4 && kh * kw <= 64 && kw >= 4 && span * h * wd * cin * 4 < (1L << 31)) seg = -1;      // the stem: one tap per k-slot
     launch_tiles<ConvLoader, ConvLoaderB, ConvLoaderTap, ConvArgs>(a, w, (int)K, (int)M, cout, (int)K, ep, s, seg);
-    timing_end(slot, 2.0 * (double)M * cout * (double)kh * kw * (alg_cin > 0 ? alg_cin : cin), s);
+    timing_end(slot, 2.0 * (double)M * cout * (double)kh * kw * (alg_cin > 0 ? alg_cin : cin), s, t_executed);
     RPG_CHECK_LAUNCH("conv2d_bn_act");
     return RPG_OK;
 }
@@ -1008,7 +1041,7 @@ int launch_linear(const GatherSrc& src, const float* weight, const float* bias, 
         if (rows <= 0 || rows * src.ld[i] * 4 >= (1L << 31)) seg = 0;
     }
     launch_tiles<GatherLoader, GatherLoaderB, GatherLoaderB, GatherArgs>(a, weight, K, m, n_out, K, ep, s, seg);
-    timing_end(slot, 2.0 * (double)m * n_out * (double)K, s);
+    timing_end(slot, 2.0 * (double)m * n_out * (double)K, s, t_executed);
     RPG_CHECK_LAUNCH("linear_gather");
     return RPG_OK;
 }
@@ -1035,6 +1068,20 @@ extern "C" int rpg_linear_gather_f32(int n_src, const float* const* a, const int
         src.width[i] = width[i];
     }
     return rpg::launch_linear(src, weight, bias, residual, out, m, n_out, relu, rpg::as_stream(stream));
+}
+
+extern "C" int rpg_release_scratch(void) {
+    if (hipDeviceSynchronize() != hipSuccess) {
+        rpg::set_last_error("release_scratch", hipGetLastError());
+        return RPG_ERR_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    for (auto& kv : g_scratch)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    g_scratch.clear();
+    for (float* p : g_retired) (void)hipFree(p);
+    g_retired.clear();
+    return RPG_OK;
 }
 
 extern "C" int rpg_set_tuning(int key, int value) {

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(GP_NT) void graph_prepare_kernel(const int64_t* __r
             perm[b + j + 1] = key;
         }
     }
-    if (tid == 0) *status = s_bad;
+    if (tid == 0 && s_bad) atomicAdd(status, s_bad);     // accumulates: the host zeroes it when it wants a fresh count
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -15,7 +15,9 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 // Kernel timing hooks (timing.hip).  begin() returns a slot (or -1 when timing is disabled).
 int timing_begin(int klass, hipStream_t s);
-void timing_end(int slot, double work, hipStream_t s);
+// work = algorithmic work of the launch (FLOP / bytes); executed = FLOP the matrix pipe really issues for it
+// (padded tiles, Winograd's reduced multiply count); 0 = same as work
+void timing_end(int slot, double work, hipStream_t s, double executed = 0.0);
 
 #define RPG_CHECK_LAUNCH(where)                         \
     do {                                                \
@@ -49,8 +51,21 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
 // 2-MiB-congruent buffers vs 272 us with >= 68 KB of skew between them (tools/probes/alias_probe.py).
 constexpr size_t kWorkspaceSkew = 260 * 1024 + 4096;
 
-// per-stream scratch for split-K partial tiles (grown on demand; consumers run in stream order) and the CU count
+// Scratch for split-K / stream-K partial tiles (consumers run in stream order).  Inside a composite forward it is a
+// slice of the CALLER's workspace (ScratchScope, set for the duration of the host-side call; a request that does not fit
+// returns null and the launcher simply does not split).  The fine-grained entry points have no workspace argument:
+// they draw on a library-owned pool, one block per (device, stream), which only ever grows, never while the stream is
+// being captured into a HIP graph, and whose old blocks stay alive until rpg_release_scratch().
 float* stream_scratch(hipStream_t s, size_t bytes);
+struct ScratchScope {
+    ScratchScope(void* p, size_t bytes);
+    ~ScratchScope();
+    ScratchScope(const ScratchScope&) = delete;
+    ScratchScope& operator=(const ScratchScope&) = delete;
+};
+// upper bound of what one launch asks stream_scratch for (stream-K: < 2 partial tiles of 64 KB per resident workgroup,
+// <= 3 workgroups per CU; Winograd split-K tail: <= one 128-KB partial tile per CU)
+size_t split_scratch_bytes();
 int num_cus();
 bool wino_enabled();
 // true if the composite forward should route this 3x3/stride-1 convolution to launch_conv_wino (enabled, shape

@@ -11,7 +11,7 @@ namespace {
 struct Slot {
     hipEvent_t beg, end;
     int klass;
-    double work;
+    double work, executed;
 };
 constexpr int MAX_SLOTS = 16384;
 std::mutex g_mu;
@@ -40,14 +40,16 @@ int timing_begin(int klass, hipStream_t s) {
     Slot& sl = g_slots[g_used];
     sl.klass = klass;
     sl.work = 0.0;
+    sl.executed = 0.0;
     (void)hipEventRecord(sl.beg, s);
     return g_used++;
 }
 
-void timing_end(int slot, double work, hipStream_t s) {
+void timing_end(int slot, double work, hipStream_t s, double executed) {
     if (slot < 0) return;
     std::lock_guard<std::mutex> lk(g_mu);
     g_slots[slot].work = work;
+    g_slots[slot].executed = executed > 0.0 ? executed : work;
     (void)hipEventRecord(g_slots[slot].end, s);
 }
 
@@ -64,13 +66,20 @@ extern "C" int rpg_timing_enable(int enable) {
 }
 
 extern "C" int rpg_timing_read(double* ms, long long* launches, double* work) {
+    return rpg_timing_read_ex(ms, launches, work, nullptr);
+}
+
+extern "C" int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* executed) {
     if (!ms || !launches || !work) return RPG_ERR_BAD_ARG;
     if (hipDeviceSynchronize() != hipSuccess) {
         rpg::set_last_error("timing_read", hipGetLastError());
         return RPG_ERR_LAUNCH;
     }
     std::lock_guard<std::mutex> lk(g_mu);
-    for (int k = 0; k < RPG_TIMER_COUNT; ++k) { ms[k] = 0.0; launches[k] = 0; work[k] = 0.0; }
+    for (int k = 0; k < RPG_TIMER_COUNT; ++k) {
+        ms[k] = 0.0; launches[k] = 0; work[k] = 0.0;
+        if (executed) executed[k] = 0.0;
+    }
     for (int i = 0; i < g_used; ++i) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, g_slots[i].beg, g_slots[i].end) != hipSuccess) continue;
@@ -79,6 +88,7 @@ extern "C" int rpg_timing_read(double* ms, long long* launches, double* work) {
         ms[k] += t;
         launches[k] += 1;
         work[k] += g_slots[i].work;
+        if (executed) executed[k] += g_slots[i].executed;
     }
     g_used = 0;
     return RPG_OK;

@@ -661,15 +661,18 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
     if (M >= (1L << 31) || (long)h * w * cin * 4 * 67 >= (1L << 31) || 6L * cout * 3 * cin * 4 >= (1L << 31) ||
         (32L / tw + 3) * w * cout * 4 >= (1L << 31))
         return RPG_ERR_BAD_ARG;
-    static bool attr = false;
-    if (!attr) {
+    int dev = 0;                                   // function attributes are per device
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    static bool attr[64] = {};
+    if (!attr[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino43_conv_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr = true;
+        attr[dev] = true;
     }
     const int tn = (cout + BN - 1) / BN;
     Epi ep{scale, shift, residual, y, relu};
     const int slot = timing_begin(RPG_TIMER_CONV_WINO, s);
+    double executed = 0.0;                 // matrix-pipe FLOP: workgroups x K steps x 48 MFMAs x waves x 4096
     const long tm8 = (M + BMT8 - 1) / BMT8;
     const bool fits8 = (long)h * w * cin * 4 * 131 < (1L << 31);     // a workgroup's 128 tiles span at most 129 images
     if (fits8 && (g_wino == 3 || (g_wino == 1 && tm8 * tn >= 8))) {
@@ -677,16 +680,17 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
         // The tiles beyond the last full round of CUs would cost a whole extra round (784 tiles on 256 CUs: a 4th
         // round for 2 % of the work): they are cut along K into floor(CUs / tail) parts (>= 4 K steps each) whose partial
         // tiles a small fix-up kernel adds in k order.
-        static bool attr8 = false;
-        if (!attr8) {
+        static bool attr8[64] = {};
+        if (!attr8[dev]) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino43_conv8_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino43_conv8_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
-            attr8 = true;
+            attr8[dev] = true;
         }
         const long T = tm8 * tn;
         const int S = num_cus(), nk = 3 * ((cin + BK - 1) / BK);
+        executed = (double)T * nk * 48.0 * 8.0 * 4096.0;
         long t_main = T;
         Split sp{0, 1, nullptr};
         const long tail = T % S;
@@ -709,9 +713,10 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
         }
     } else {
         const int tm = (int)((M + BMT - 1) / BMT);
+        executed = (double)tm * tn * (3 * ((cin + BK - 1) / BK)) * 48.0 * 4.0 * 4096.0;
         hipLaunchKernelGGL(wino43_conv_kernel, dim3(tm * tn), dim3(NT), LDS_BYTES, s, x, u, h, w, cin, cout, tw, (int)M, ep, tn);
     }
-    timing_end(slot, 2.0 * (double)n * h * w * cout * 9.0 * cin, s);      // algorithmic (direct-convolution) FLOP
+    timing_end(slot, 2.0 * (double)n * h * w * cout * 9.0 * cin, s, executed);      // algorithmic = direct-convolution FLOP
     RPG_CHECK_LAUNCH("conv3x3_wino43");
     return RPG_OK;
 }

@@ -99,22 +99,41 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 32
         chunk = [graphs[i] for i in range(b0, min(hi, b0 + micro_batch))]
         batch = Batch.from_data_list(chunk).to(device, non_blocking=True)
         _, rel, edge_index = model(batch)
-        if edge_index.shape[1] != sum(c.edge_index.shape[1] for c in chunk):          # kNN graph returned by the model
-            raise NotImplementedError("per-graph slicing of model-built (kNN) edge lists")
+        # a model-built edge list (kNN graph: the reference's default --knn 4, test.py:308, posenet.py:1047-1048) comes
+        # back instead of the stored one: it travels to the host with the poses and is cut per graph in finish()
+        model_built = edge_index is not batch.edge_index
         if on_gpu:
             host = torch.empty(rel.shape, dtype=rel.dtype, pin_memory=True)
             host.copy_(rel, non_blocking=True)
+            host_ei = None
+            if model_built:
+                host_ei = torch.empty(edge_index.shape, dtype=edge_index.dtype, pin_memory=True)
+                host_ei.copy_(edge_index, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
         else:
-            host, ev = rel, None
-        return chunk, host, ev
+            host, host_ei, ev = rel, (edge_index if model_built else None), None
+        return chunk, host, host_ei, ev
 
     def finish(item):
-        chunk, host, ev = item
+        chunk, host, host_ei, ev = item
         if ev is not None:
             ev.synchronize()
+        check = getattr(model, "check_edge_index", None)
+        if check is not None:
+            check()            # the bad-edge counters were copied before `ev`: no further wait (IndexError like the reference)
         rel = host.numpy()
+        if host_ei is not None:
+            ei = host_ei.numpy()
+            sizes = np.asarray([g.num_nodes for g in chunk])
+            first = np.concatenate([[0], np.cumsum(sizes)])
+            gid = np.searchsorted(first, ei[1], side="right") - 1          # graph of every edge (by its target node)
+            for k, g in enumerate(chunk):
+                cols = np.flatnonzero(gid == k)                            # batch order kept: test.py takes the FIRST hit
+                p, t = query_pose(rel[cols], g.y.cpu().numpy(), ei[:, cols] - first[k], pose_m, pose_s, ref_node)
+                preds.append(p)
+                targs.append(t)
+            return
         e0 = 0
         for g in chunk:
             e = g.edge_index.shape[1]
@@ -140,10 +159,25 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 32
     return errors(pred, targ)
 
 
-def save_poses(path, result: EvalResult, rel_paths: Optional[Iterable] = None) -> None:
-    """The .npz of test.py:38-42 (same field names)."""
-    rel_paths = list(rel_paths) if rel_paths is not None else [f"graph_{i:06d}" for i in range(len(result.pred_poses))]
-    assert len(rel_paths) == len(result.pred_poses)
+def seven_scenes_rel_paths(file_list: Sequence, dataset_filenames: Sequence, dataset_dir) -> List[str]:
+    """The ``rel_path`` column eval_RP records for 7-Scenes (test.py:255-260): graph file ``data_<linear id>.pt`` ->
+    ``dataset_filenames[linear id]`` (the colour frames of the TestSplit sequences in order, test.py:103-114) relative to
+    the dataset directory."""
+    import os
+    out = []
+    for fname in file_list:
+        stem = os.path.splitext(os.path.basename(str(fname)))[0]
+        linear_id = int(stem.split("_")[-1])
+        out.append(os.path.relpath(str(dataset_filenames[linear_id]), str(dataset_dir)))
+    return out
+
+
+def save_poses(path, result: EvalResult, rel_paths: Iterable) -> None:
+    """The .npz of test.py:38-42 (same field names, same length assertion).  ``rel_paths``: one entry per graph, for
+    7-Scenes ``seven_scenes_rel_paths(...)``."""
+    rel_paths = [str(p) for p in rel_paths]
+    assert len(rel_paths) == len(result.pred_poses), \
+        f"len(rel_paths): {len(rel_paths)} != {len(result.pred_poses)} len(pred_poses)"
     np.savez(path, rel_path=rel_paths, abs_t=result.pred_poses[:, :3], abs_q=result.pred_poses[:, 3:],
              targ_t=result.targ_poses[:, :3], targ_q=result.targ_poses[:, 3:])
 

@@ -14,7 +14,6 @@ from __future__ import annotations
 import glob
 import os
 import pickle
-import re
 from typing import Any, Dict, List
 
 import torch
@@ -43,17 +42,36 @@ class _Shell:
 
 _SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray",
                   "complex", "slice", "range", "object"}
+# Everything a tensor-carrying pickle legitimately names, as explicit (module, name) pairs.  A module-prefix rule is not
+# enough: `torch.utils.collect_env.run`, `torch.hub.load`, `numpy.testing...runstring` live under the same roots and
+# execute code when called from a REDUCE opcode.
+_SAFE_GLOBALS = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch.storage", "_load_from_bytes"), ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "dtype"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
+    ("torch.serialization", "_get_layout"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+}
+_TORCH_STORAGES = {f"{t}Storage" for t in ("Float", "Double", "Half", "BFloat16", "Long", "Int", "Short", "Char", "Byte",
+                                            "Bool", "ComplexFloat", "ComplexDouble")}
+_TORCH_DTYPES = {"float32", "float64", "float16", "bfloat16", "int64", "int32", "int16", "int8", "uint8", "bool",
+                 "complex64", "complex128", "float", "double", "half", "long", "int", "short"}
 
 
 class _Unpickler(pickle.Unpickler):
-    """PyG classes -> neutral shells; otherwise only tensor-rebuilding helpers of torch / numpy / collections and plain
-    builtin containers are resolved (a sample file is data: nothing else has any business being unpickled from it)."""
+    """PyG classes -> neutral shells; apart from those only an explicit allow-list of tensor-rebuilding helpers, typed
+    storages, dtypes and plain containers resolves.  A sample file is data: a pickle that names anything else (any
+    callable that could run code from a REDUCE opcode) is refused."""
 
     def find_class(self, module: str, name: str):
         if module == "torch_geometric" or module.startswith("torch_geometric."):
             return type(name, (_Shell,), {"__module__": module})
-        root = module.split(".")[0]
-        if root in ("torch", "numpy", "collections") or (module == "builtins" and name in _SAFE_BUILTINS):
+        if ((module, name) in _SAFE_GLOBALS or (module == "builtins" and name in _SAFE_BUILTINS) or
+                (module == "torch" and (name in _TORCH_STORAGES or name in _TORCH_DTYPES))):
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"refusing to unpickle {module}.{name} from a graph sample file")
 
@@ -97,19 +115,18 @@ def load_graph(path: str) -> Data:
 
 
 def processed_files(root: str) -> List[str]:
-    """The reference's file list: ``processed/data_*`` under the dataset root (dataset_7Scenes_multi.py:69-75), ordered by
-    the integer in the name (equal to lexicographic order for the zero-padded 7-Scenes names)."""
+    """The reference's file list: ``processed/data_*`` under the dataset root in the order of ``self.file_list.sort()``
+    (dataset_7Scenes_multi.py:69-75,116; dataset_Cambridge_multi.py:72), i.e. LEXICOGRAPHIC on the file name.  For the
+    zero-padded 7-Scenes names (``data_%06d.pt``) that is numeric order; for Cambridge's unpadded ``data_%d.pt`` it is
+    not (data_10.pt sorts before data_2.pt) and evaluation order / the i-th prediction follow the reference."""
     files = glob.glob(os.path.join(root, "processed", "data_*.pt"))
-
-    def key(p):
-        m = re.search(r"data_(\d+)\.pt$", p)
-        return int(m.group(1)) if m else -1
-    return sorted(files, key=key)
+    return sorted(files, key=os.path.basename)
 
 
 def load_checkpoint_state_dict(path: str, map_location="cpu") -> Dict[str, torch.Tensor]:
-    """``torch.load(path)['model_state_dict']`` (test.py:347); a bare state dict is accepted too."""
-    ck = torch.load(path, map_location=map_location, weights_only=False)
+    """``torch.load(path)['model_state_dict']`` (test.py:347); a bare state dict is accepted too.  Loaded through the
+    same allow-list as the sample files (a checkpoint is tensors, ints and dicts: utils.py:22-31)."""
+    ck = torch.load(path, map_location=map_location, pickle_module=_PickleModule, weights_only=False)
     if isinstance(ck, dict) and "model_state_dict" in ck:
         return ck["model_state_dict"]
     return ck

@@ -255,9 +255,15 @@ def timing_enable(on: bool) -> None:
 
 def timing_read() -> Dict[str, Dict[str, float]]:
     n = len(L.TIMER_NAMES)
-    ms, cnt, work = (C.c_double * n)(), (C.c_longlong * n)(), (C.c_double * n)()
-    L.check(L.lib().rpg_timing_read(ms, cnt, work), "timing_read")
-    return {name: {"ms": ms[i], "launches": int(cnt[i]), "work": work[i]} for i, name in enumerate(L.TIMER_NAMES)}
+    ms, cnt, work, ex = (C.c_double * n)(), (C.c_longlong * n)(), (C.c_double * n)(), (C.c_double * n)()
+    L.check(L.lib().rpg_timing_read_ex(ms, cnt, work, ex), "timing_read")
+    return {name: {"ms": ms[i], "launches": int(cnt[i]), "work": work[i], "executed": ex[i]}
+            for i, name in enumerate(L.TIMER_NAMES)}
+
+
+def release_scratch() -> None:
+    """Free the library-owned split-K scratch pool of the fine-grained entry points (synchronises)."""
+    L.check(L.lib().rpg_release_scratch(), "release_scratch")
 
 
 TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9

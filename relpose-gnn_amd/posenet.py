@@ -15,6 +15,14 @@ constructor / forward flags of the reference -- ``use_attention`` (posenet.py:10
 same kernels with a few more fine-grained calls.  The reference's always-on dropout (``F.dropout`` without ``training=``, posenet.py:1073-1075) is honoured: with
 ``droprate>0`` the node/edge features come back from the GNN call, ``F.dropout`` is applied, and the heads kernel runs on
 the result; parity tests use ``droprate=0``.  Everything runs on the GPU; CPU tensors raise (no fallback).
+
+Index validation.  The reference's aten indexing raises ``IndexError`` for a node id outside ``[0, N)``.  Here every call
+is validated on the device (``rpg_graph_prepare`` counts the offending edges, clamps them and leaves them out of the
+aggregation, so nothing reads out of bounds) and the count travels to pinned host memory with an asynchronous copy
+behind the kernels.  ``index_check = "deferred"`` (default) never blocks inside ``forward``: the count of call i is looked
+at when call i+1 starts (by then a reference-style caller has already synchronised through ``.cpu()``), in
+``check_edge_index()`` and by ``evaluate_stream`` right after its own device-to-host event; ``index_check = "sync"``
+reads it back before returning, like the reference, at the price of one device synchronisation per call.
 """
 from __future__ import annotations
 
@@ -115,7 +123,11 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         self._gnn_dtype = "f32"
         self._extra: Dict[str, torch.Tensor] = {}
         self._gnn_ws: Dict[Tuple, torch.Tensor] = {}
-        self._checked_edges: Dict[Tuple, bool] = {}
+        self.index_check = "deferred"            # "deferred" | "sync" (see the module docstring)
+        self._status: Optional[torch.Tensor] = None          # device int32 [8]: bad-edge counters, one per stream slot
+        self._status_host: Optional[torch.Tensor] = None     # pinned mirror
+        self._status_event: Optional[torch.cuda.Event] = None
+        self._status_pending = False
 
     @property
     def encoder_dtype(self) -> str:
@@ -148,7 +160,6 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         self._gnn_bf16, self._gnn_bf16_ptrs = None, None
         self._extra = {}
         self._gnn_ws.clear()
-        self._checked_edges.clear()
 
     def _apply(self, fn, *a, **k):
         if hasattr(self, "_enc"):
@@ -178,6 +189,55 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
                 self._extra["att_w"], self._extra["att_b"] = sd["att.W.weight"].float().contiguous(), sd["att.W.bias"].float().contiguous()
             self._gnn_packed = pack_gnn(sd)
             self._gnn_ptrs = _L.ptr_array([t.data_ptr() for t in self._gnn_packed])
+        if self._gnn_dtype == "bf16" and self._gnn_bf16 is None:
+            self._gnn_bf16 = pack_gnn_bf16(self._gnn_packed)
+            self._gnn_bf16_ptrs = _L.ptr_array([t.data_ptr() for t in self._gnn_bf16])
+
+    # ---- edge_index validation without a host synchronisation ----------------------------------------------------
+    def _status_buffers(self, dev) -> torch.Tensor:
+        if self._status is None or self._status.device != dev:
+            self._status = torch.zeros(8, dtype=torch.int32, device=dev)
+            self._status_host = torch.zeros(8, dtype=torch.int32).pin_memory()
+            self._status_event = torch.cuda.Event()
+            self._status_pending = False
+        return self._status
+
+    def _raise_bad_edges(self, bad: int):
+        self._status.zero_()
+        self._status_pending = False
+        raise IndexError(f"edge_index has {bad} edge(s) with a node id outside its graph group / [0, N) "
+                         "(detected on the device; with index_check='deferred' this refers to an EARLIER forward call)")
+
+    def _poll_status(self, block: bool) -> None:
+        """Look at the counters of the previous call(s) if their copy has landed (or wait for it when ``block``)."""
+        if not self._status_pending:
+            return
+        if block:
+            self._status_event.synchronize()
+        elif not self._status_event.query():
+            return
+        self._status_pending = False
+        bad = int(self._status_host.sum())
+        if bad:
+            self._raise_bad_edges(bad)
+
+    def _publish_status(self) -> None:
+        """Enqueue the counters' copy to pinned memory behind this call's kernels (current stream)."""
+        if torch.cuda.is_current_stream_capturing():
+            return                                # a captured forward is validated by its eager warm-up call
+        if self.index_check == "sync":
+            bad = int(self._status.sum().item())
+            if bad:
+                self._raise_bad_edges(bad)
+            return
+        self._status_host.copy_(self._status, non_blocking=True)
+        self._status_event.record()
+        self._status_pending = True
+
+    def check_edge_index(self) -> None:
+        """Block until every forward issued so far has reported, and raise IndexError if any had an edge with a node id
+        out of range (the error the reference's indexing raises at the call itself)."""
+        self._poll_status(block=True)
 
     def _gnn_call(self, lib, feat, esrc_ptr, edst_ptr, node_off, n, e, abs_pose, rel_pose, node_f, edge_f, status, slot):
         d = feat.shape[1]
@@ -190,9 +250,6 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
             self._gnn_ws[slot] = ent
         ws = ent[1]
         if self._gnn_dtype == "bf16":
-            if self._gnn_bf16 is None:
-                self._gnn_bf16 = pack_gnn_bf16(self._gnn_packed)
-                self._gnn_bf16_ptrs = _L.ptr_array([t.data_ptr() for t in self._gnn_bf16])
             rc = lib.rpg_gnn_forward_bf16(self._gnn_ptrs, len(self._gnn_packed), self._gnn_bf16_ptrs, len(self._gnn_bf16),
                                           feat.data_ptr(), esrc_ptr, edst_ptr, node_off, n, e, d, int(self.gnn_recursion),
                                           abs_pose.data_ptr(), rel_pose.data_ptr(),
@@ -208,11 +265,51 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
                                      ws.numel(), torch.cuda.current_stream().cuda_stream)
         _L.check(rc, "gnn_forward")
 
+    @staticmethod
+    def _graph_sizes(data, n_total: int, e_total: int):
+        """(nodes per graph, edges per graph) as host lists, or None.  Sources, cheapest first: this package's
+        ``Batch.graph_sizes``; the host-side slice tables a ``torch_geometric`` ``Batch`` keeps from collation
+        (``_slice_dict`` in PyG 2.x, ``__slices__`` in 1.x: cumulative offsets, never moved to the GPU -- this is what the
+        reference's DataLoader hands over, testing/test.py:193); ``data.ptr`` / ``data.batch`` (device tensors: one small
+        device-to-host copy BEFORE any kernel of this call is enqueued)."""
+        gs = getattr(data, "graph_sizes", None)
+        if gs is not None:
+            return gs if sum(gs[0]) == n_total and sum(gs[1]) == e_total else None
+        for attr in ("_slice_dict", "__slices__"):
+            sl = getattr(data, attr, None)
+            if isinstance(sl, dict) and "x" in sl and "edge_index" in sl:
+                cn = [int(v) for v in torch.as_tensor(sl["x"]).tolist()]
+                ce = [int(v) for v in torch.as_tensor(sl["edge_index"]).tolist()]
+                if len(cn) == len(ce) >= 2 and cn[0] == 0 and ce[0] == 0 and cn[-1] == n_total and ce[-1] == e_total:
+                    return ([b - a for a, b in zip(cn, cn[1:])], [b - a for a, b in zip(ce, ce[1:])])
+                return None
+        ptr, batch = getattr(data, "ptr", None), getattr(data, "batch", None)
+        if torch.is_tensor(ptr) and ptr.dim() == 1 and ptr.numel() >= 2:
+            cn = [int(v) for v in ptr.tolist()]
+            nodes = [b - a for a, b in zip(cn, cn[1:])]
+        elif torch.is_tensor(batch) and batch.dim() == 1 and batch.numel() == n_total and n_total > 0:
+            nodes = [int(v) for v in torch.bincount(batch).tolist()]
+        else:
+            return None
+        if sum(nodes) != n_total or len(nodes) < 2 or not torch.is_tensor(batch) or batch.numel() != n_total:
+            return None
+        ei = data.edge_index
+        gid = batch[ei[0]]                                     # graph of every edge (PyG keeps a graph's edges together)
+        if e_total > 1 and bool((gid[1:] < gid[:-1]).any()):
+            return None                                        # edges not grouped by graph: no contiguous cut exists
+        edges = [int(v) for v in torch.bincount(gid, minlength=len(nodes)).tolist()]
+        return (nodes, edges) if sum(edges) == e_total else None
+
     def _partition(self, data, n_total: int, e_total: int):
         """Contiguous groups of whole graphs, one per stream: [(n0, n1, e0, e1), ...] or None (single stream)."""
-        gs = getattr(data, "graph_sizes", None)
-        parts = int(self.hip_streams)
-        if gs is None or parts < 2 or len(gs[0]) < 2 * parts or sum(gs[0]) != n_total or sum(gs[1]) != e_total:
+        parts = min(int(self.hip_streams), 8)                  # one bad-edge counter per slot (self._status)
+        if parts < 2:
+            return None
+        ng = getattr(data, "num_graphs", None)
+        if isinstance(ng, int) and ng < 2 * parts:             # e.g. the reference's batch_size=1 loop: nothing to cut
+            return None
+        gs = self._graph_sizes(data, n_total, e_total)
+        if gs is None or len(gs[0]) < 2 * parts:
             return None
         nodes, edges = gs
         out, g0, n0, e0 = [], 0, 0, 0
@@ -234,8 +331,12 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         if x.dtype != torch.float32:
             raise TypeError(f"data.x must be float32 (the reference's input dtype), got {x.dtype}")
         lib = _L.lib()
+        self._poll_status(block=False)            # bad-edge report of the previous call, if it has landed
         x = x.view(x.size(0), 3, self.input_img_height, -1)                       # posenet.py:1035
+        # all weight packing happens here, on the caller's stream, BEFORE any side stream is forked off it
         self._pack_gnn()
+        self._enc.ensure_packed(self.feature_extractor.state_dict, "", x.device)
+        self._status_buffers(x.device)
         fast = self.use_AP and not self.use_attention and k is None and self.knn <= 0 and not self.droprate > 0
         parts = self._partition(data, x.size(0), edge_index.size(1)) if fast else None
         if parts is not None and edge_index.dtype == torch.int64 and edge_index.dim() == 2 and edge_index.is_contiguous():
@@ -264,22 +365,14 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         dev = feat.device
         abs_pose = torch.empty((n, 6), dtype=torch.float32, device=dev)
         rel_pose = torch.empty((e, 6), dtype=torch.float32, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        status = self._status[0:1]
         drop = self.droprate > 0
         want_feats = drop or not self.use_AP
         node_f = torch.empty((n, d), dtype=torch.float32, device=dev) if want_feats else None
         edge_f = torch.empty((e, d), dtype=torch.float32, device=dev) if drop else None
         self._gnn_call(lib, feat, ei.data_ptr(), ei.data_ptr() + 8 * e, 0, n, e, abs_pose, rel_pose, node_f, edge_f, status, 0)
 
-        # index validation: the reference would raise from aten indexing; check once per edge_index tensor
-        ekey = (ei.data_ptr(), e, n, ei._version)
-        if ekey not in self._checked_edges:
-            bad = int(status.item())
-            if bad:
-                raise IndexError(f"edge_index has {bad} edge(s) with a node id outside [0, {n})")
-            if len(self._checked_edges) > 64:
-                self._checked_edges.clear()
-            self._checked_edges[ekey] = True
+        self._publish_status()                    # every call is validated; nothing blocks in "deferred" mode
 
         t = self._gnn_packed
         if drop:                                                                  # posenet.py:1073-1075 (always on)
@@ -303,7 +396,7 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         cur = torch.cuda.current_stream()
         abs_pose = torch.empty((n_total, 6), dtype=torch.float32, device=dev)
         rel_pose = torch.empty((e_total, 6), dtype=torch.float32, device=dev)
-        status = torch.zeros(len(parts), dtype=torch.int32, device=dev)
+        status = self._status
         ready = torch.cuda.Event()
         ready.record(cur)
         base = edge_index.data_ptr()
@@ -317,12 +410,5 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
                 feat.record_stream(st)
         for st in self._streams[:len(parts)]:
             cur.wait_stream(st)
-        ekey = (base, e_total, n_total, edge_index._version)
-        if ekey not in self._checked_edges:
-            bad = int(status.sum().item())
-            if bad:
-                raise IndexError(f"edge_index has {bad} edge(s) with a node id outside its graph group / [0, {n_total})")
-            if len(self._checked_edges) > 64:
-                self._checked_edges.clear()
-            self._checked_edges[ekey] = True
+        self._publish_status()
         return abs_pose, rel_pose, edge_index

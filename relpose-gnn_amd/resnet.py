@@ -59,23 +59,30 @@ class EncoderRunner:
             self.dtype = dtype
             self.invalidate()
 
+    def ensure_packed(self, state_dict_fn, prefix: str, device) -> None:
+        """Pack the weights for the C ABI (layout permutes, BatchNorm folds, Winograd transforms) on the CURRENT stream.
+        Callers that spread ``run`` over side streams call this first, on the stream those side streams are forked
+        from, so that the packing kernels are ordered before every reader."""
+        if self._packed is not None:
+            return
+        with torch.no_grad():
+            sd = {k: v.detach() for k, v in state_dict_fn().items()}
+            if any(v.device != device for v in sd.values() if v.is_floating_point()):
+                raise RuntimeError("encoder weights and input are on different devices")
+            from . import ops
+            if self.dtype == "bf16":
+                self._packed = pack_resnet_bf16(sd, prefix)
+            else:
+                self._packed = pack_resnet(sd, prefix, wino_fn=ops.wino43_transform_weights)
+        self._ptrs = L.ptr_array([None if t is None else t.data_ptr() for t in self._packed[0]])
+
     def run(self, state_dict_fn, prefix: str, x_nchw: torch.Tensor, slot: int = 0) -> torch.Tensor:
         if not x_nchw.is_cuda:
             raise RuntimeError("the encoder runs on the GPU only (HIP kernels, no CPU fallback); got " + str(x_nchw.device))
         if x_nchw.dtype != torch.float32 or x_nchw.dim() != 4 or x_nchw.shape[1] != 3:
             raise ValueError("expected fp32 [N,3,H,W]")
         lib = L.lib()
-        if self._packed is None:
-            with torch.no_grad():
-                sd = {k: v.detach() for k, v in state_dict_fn().items()}
-                if any(v.device != x_nchw.device for v in sd.values() if v.is_floating_point()):
-                    raise RuntimeError("encoder weights and input are on different devices")
-                from . import ops
-                if self.dtype == "bf16":
-                    self._packed = pack_resnet_bf16(sd, prefix)
-                else:
-                    self._packed = pack_resnet(sd, prefix, wino_fn=ops.wino43_transform_weights)
-            self._ptrs = L.ptr_array([None if t is None else t.data_ptr() for t in self._packed[0]])
+        self.ensure_packed(state_dict_fn, prefix, x_nchw.device)
         tensors, blocks, planes = self._packed
         x = x_nchw.contiguous()
         n, _, h, w = x.shape

@@ -57,9 +57,43 @@ def test_evaluate_stream_and_npz(tmp_path):
         assert np.allclose(res.pred_poses[i, :3], exp[:3], atol=1e-6)
         assert np.allclose(res.pred_poses[i, 3:], E.qexp(exp[3:]), atol=1e-6)
     assert len(res.summary()) == 4 and res.median_t == float(np.median(res.t_loss))
-    E.save_poses(tmp_path / "out.npz", res)
+    # 7-Scenes rel_path bookkeeping of test.py:255-260: data_<linear id>.pt -> the linear id-th colour frame of the split
+    frames = [f"/data/7scenes/chess/seq-03/frame-{i:06d}.color.png" for i in range(12)]
+    files = [f"/graphs/chess_fc8_sp5_test/processed/data_{i:06d}.pt" for i in (0, 3, 4, 7, 11)]
+    rel = E.seven_scenes_rel_paths(files, frames, "/data/7scenes")
+    assert rel[1] == "chess/seq-03/frame-000003.color.png" and rel[4].endswith("frame-000011.color.png")
+    E.save_poses(tmp_path / "out.npz", res, rel)
     z = np.load(tmp_path / "out.npz")
     assert set(z.files) == {"rel_path", "abs_t", "abs_q", "targ_t", "targ_q"} and z["abs_q"].shape == (5, 4)
+    assert list(z["rel_path"]) == rel
+    with pytest.raises(AssertionError):
+        E.save_poses(tmp_path / "bad.npz", res, rel[:-1])                # the reference asserts equal lengths (test.py:40)
+
+
+class _FakeKnnModel:
+    """Returns its OWN edge list (every node's single nearest-by-index neighbour ring, grouped by target like
+    torch_cluster.knn_graph), as the reference model does with knn > 0 (posenet.py:1047-1048,1088-1089)."""
+
+    def __call__(self, batch):
+        n = batch.x.shape[0]
+        tgt = torch.arange(n).repeat_interleave(2)
+        base = (tgt // 8) * 8
+        src = base + (tgt - base + torch.tensor([1, 3]).repeat(n)) % 8
+        ei = torch.stack([src, tgt])
+        return None, batch.y[ei[1]] - batch.y[ei[0]] + 0.01, ei
+
+
+def test_evaluate_stream_with_model_built_edges():
+    """The reference's default --knn 4 (test.py:308): eval_RP post-processes the edge list the MODEL returns."""
+    rng = np.random.RandomState(2)
+    graphs = [Data(x=torch.zeros(8, 12), edge_index=fc_edge_index(8), y=torch.from_numpy(rng.randn(8, 6) * 0.2).float())
+              for _ in range(5)]
+    res = E.evaluate_stream(_FakeKnnModel(), graphs, "cpu", micro_batch=2)
+    for i, g in enumerate(graphs):                     # first edge into node 0 is (1 -> 0): pred = y[1] - (y[0]-y[1]+0.01)
+        y = g.y.numpy().astype(np.float64)
+        exp = y[1] - (y[0] - y[1] + 0.01)
+        assert np.allclose(res.pred_poses[i, :3], exp[:3], atol=1e-6)
+        assert np.allclose(res.pred_poses[i, 3:], E.qexp(exp[3:]), atol=1e-6)
 
 
 def _fake_pyg(layout):
@@ -102,7 +136,8 @@ def test_graph_reader_without_pyg(tmp_path, layout):
         for n in mods:
             sys.modules.pop(n, None)
     files = rio.processed_files(str(tmp_path))
-    assert [os.path.basename(f) for f in files] == ["data_0.pt", "data_1.pt", "data_2.pt", "data_10.pt"]
+    # self.file_list.sort() of the reference is lexicographic (dataset_Cambridge_multi.py:72): data_10 before data_2
+    assert [os.path.basename(f) for f in files] == ["data_0.pt", "data_1.pt", "data_10.pt", "data_2.pt"]
     d = rio.load_graph(files[3])
     assert torch.equal(d.x, x) and torch.equal(d.edge_index, ei) and torch.equal(d.y, y) and d.edge_attr.shape == (56, 6)
     assert "torch_geometric" not in sys.modules
@@ -115,6 +150,15 @@ def test_graph_reader_without_pyg(tmp_path, layout):
     with pytest.raises(Exception) as exc:
         rio.load_graph(str(evil))
     assert "refusing to unpickle" in str(exc.value)
+
+    class _Rce:                                                         # a callable UNDER the torch root
+        def __reduce__(self):
+            import torch.utils.collect_env as ce
+            return (ce.run, ("echo PWNED > " + str(tmp_path / "pwned"),))
+    torch.save({"x": x, "edge_index": ei, "f": _Rce()}, evil)
+    with pytest.raises(Exception) as exc:
+        rio.load_graph(str(evil))
+    assert "refusing to unpickle torch.utils.collect_env.run" in str(exc.value) and not (tmp_path / "pwned").exists()
 
 
 def test_checkpoint_reader(tmp_path):

@@ -144,11 +144,37 @@ def test_module_contract(dev):
     half.x = half.x.half()
     with pytest.raises(TypeError):
         m(half)
+    # a node id out of range: the reference's indexing raises IndexError.  Every call is validated on the device; the
+    # default mode reports without blocking inside forward (at check_edge_index() / the next call), "sync" at the call
     bad = _data(x, 8, dev)
     bad.edge_index = bad.edge_index.clone()
     bad.edge_index[0, 5] = 99
+    assert m.index_check == "deferred"
+    m(bad)                                                  # returns (the bad edge is clamped and left out on the device)
+    with pytest.raises(IndexError):
+        m.check_edge_index()
+    m.check_edge_index()                                    # reported once; the counter is cleared
+    m(bad)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        m(d)                                                # the NEXT call reports it too
+    a_ok, _, _ = m(d)
+    m.check_edge_index()
+    assert torch.equal(a_ok, a)
+    # the same storage refilled with different (bad) indices is validated again: nothing is cached on data_ptr
+    good = _data(x, 8, dev)
+    m(good)
+    m.check_edge_index()
+    good.edge_index[1, 7] = -3
+    m(good)
+    with pytest.raises(IndexError):
+        m.check_edge_index()
+    m.index_check = "sync"
     with pytest.raises(IndexError):
         m(bad)
+    a_ok, _, _ = m(d)
+    assert torch.equal(a_ok, a)
+    m.index_check = "deferred"
     # dropout-faithful path runs and changes the output (always-on dropout of the reference)
     m.droprate = 0.5
     a2, r2, _ = m(d)
@@ -157,6 +183,45 @@ def test_module_contract(dev):
     # determinism of the droprate=0 path
     a3, r3, _ = m(d)
     assert torch.equal(a3, a) and torch.equal(r3, r)
+
+
+@pytest.mark.parametrize("use_AP", [True, False])
+def test_dropout_always_on_with_seeded_mask(dev, use_AP):
+    """A11 (posenet.py:1073-1075): F.dropout(x, p) / F.dropout(edge_feat, p) with training=True regardless of eval().
+    The random draw cannot match across devices, but its arithmetic can be pinned: with the GPU generator re-seeded, the
+    masks the module drew are reproduced by F.dropout on tensors of the same shapes in the same order, and the oracle's
+    heads on the identically masked features must equal the module's outputs.  Also: keep probability and 1/(1-p) scale."""
+    import relpose_gnn_amd.synth as S
+    from oracle import posenet_ref as O
+    from relpose_gnn_amd.posenet import PoseNetX_R2
+    from relpose_gnn_amd.resnet import ResNet
+    D, p = 64, 0.5
+    planes, blocks = (8, 16, 32, 64), (1, 1, 1, 1)
+    m = PoseNetX_R2(ResNet(blocks, planes), droprate=p, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D,
+                    input_img_height=32, use_gnn=True, knn=-1, use_AP=use_AP, gnn_recursion=2)
+    sd = S.synth_state_dict(S.posenet_r2_param_shapes(D, D, D, planes, blocks, use_AP=use_AP), seed=1)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()                                    # eval() does NOT switch the reference's dropout off
+    x = S.synth_images(24, 32, 40, seed=3)
+    d = _data(x, 8, dev)
+    n, e = 24, 3 * 56
+    torch.cuda.manual_seed(1234)
+    a, r, _ = m(d)
+    torch.cuda.manual_seed(1234)
+    ones_n, ones_e = torch.ones(n, D, device=dev), torch.ones(e, D, device=dev)
+    mask_n = torch.nn.functional.dropout(ones_n, p=p)       # same generator state, same shapes, same order as forward
+    mask_e = torch.nn.functional.dropout(ones_e, p=p)
+    vals = torch.unique(torch.cat([mask_n.flatten(), mask_e.flatten()])).tolist()
+    assert vals == [0.0, 1.0 / (1.0 - p)]                   # dropped -> 0, kept -> scaled by 1/(1-p)
+    keep = float((mask_e > 0).float().mean())
+    assert abs(keep - (1.0 - p)) < 0.02, keep               # 10752 draws: 4 sigma = 0.02
+    oa, orr, _ = O.posenet_forward(sd, x, d.edge_index.cpu(), 32, 2, use_AP=use_AP, node_mask=mask_n.cpu(),
+                                   edge_mask=mask_e.cpu())
+    ea, er = rel_err(a.cpu(), oa), rel_err(r.cpu(), orr)
+    _report(f"dropout_seeded_mask_use_AP_{use_AP}", ea, er)
+    assert ea < TOL and er < TOL, (ea, er)
+    a2, _, _ = m(d)                                         # a fresh draw differs (always-on)
+    assert not torch.allclose(a2, a)
 
 
 def test_batch_independence_full_width(dev):
