@@ -109,7 +109,7 @@ def cpu_baseline(budget_s: float):
                       f"(32 images 224x224 each), torch {torch.__version__} CPU fp32, {secs:.1f} s"}
 
 
-def spawn_ranks(n: int) -> int:
+def spawn_ranks(n: int, script: str = None, argv=None) -> int:
     """`python bench.py --gpus N` outside torchrun: run the N ranks as a child `torch.distributed.run` (this process has
     not initialised the GPU: nothing before this point calls into HIP) and relay rank 0's JSON line."""
     import socket
@@ -118,7 +118,7 @@ def spawn_ranks(n: int) -> int:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), script or os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None

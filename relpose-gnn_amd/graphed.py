@@ -29,8 +29,10 @@ class GraphedForward:
         side = torch.cuda.Stream(device=example.x.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):       # packs weights, sizes workspaces, validates edge_index (one sync)
+            for _ in range(max(1, warmup)):       # packs weights, sizes workspaces
                 model(self.static)
+            if hasattr(model, "check_edge_index"):
+                model.check_edge_index()          # validates the example's edge_index (one sync, before the capture)
             with torch.cuda.graph(self.graph, stream=side):
                 self.out = model(self.static)
         torch.cuda.current_stream().wait_stream(side)
@@ -44,4 +46,6 @@ class GraphedForward:
             if data.edge_index.data_ptr() != self.static.edge_index.data_ptr():
                 self.static.edge_index.copy_(data.edge_index, non_blocking=True)
         self.graph.replay()
+        if hasattr(self.model, "publish_status"):
+            self.model.publish_status()           # bad-edge counters of the replayed kernels -> model.check_edge_index()
         return self.out

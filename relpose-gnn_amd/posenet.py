@@ -210,7 +210,7 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
 
     def _poll_status(self, block: bool) -> None:
         """Look at the counters of the previous call(s) if their copy has landed (or wait for it when ``block``)."""
-        if not self._status_pending:
+        if not self._status_pending or torch.cuda.is_current_stream_capturing():
             return
         if block:
             self._status_event.synchronize()
@@ -220,6 +220,12 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         bad = int(self._status_host.sum())
         if bad:
             self._raise_bad_edges(bad)
+
+    def publish_status(self) -> None:
+        """For callers that replay a captured forward (graphed.GraphedForward): the replayed kernels keep counting bad
+        edges on the device; this enqueues the copy of the counters behind the replay."""
+        if self._status is not None:
+            self._publish_status()
 
     def _publish_status(self) -> None:
         """Enqueue the counters' copy to pinned memory behind this call's kernels (current stream)."""

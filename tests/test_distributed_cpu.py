@@ -8,6 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _free_port():
     s = socket.socket()
@@ -96,3 +98,32 @@ def test_sharded_evaluation_stream(tmp_path):
     for r in range(2):
         got = np.load(os.path.join(str(tmp_path), f"e{r}.npy"))
         assert got.shape == (7, 7) and np.allclose(got, ref, atol=1e-6)
+
+
+def test_bench_spawns_its_own_ranks(tmp_path, capsys):
+    """`python bench.py --gpus N` without a torchrun environment starts N ranks as a child process and relays rank 0's
+    JSON line.  The launcher is exercised here with a stand-in rank script on gloo (bench.py's own
+    ranks need GPUs)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("rpg_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    stub = tmp_path / "rank.py"
+    stub.write_text(
+        "import json, os, sys\n"
+        "import torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "t = torch.tensor([float(dist.get_rank() + 1)])\n"
+        "dist.all_reduce(t)\n"
+        "print('noise from rank', dist.get_rank(), flush=True)\n"
+        "if dist.get_rank() == 0:\n"
+        "    print(json.dumps({'metric': 'stub', 'value': float(t), 'n_gpus': dist.get_world_size(), 'argv': sys.argv[1:]}), flush=True)\n"
+        "dist.barrier(); dist.destroy_process_group()\n")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    rc = bench.spawn_ranks(2, script=str(stub), argv=["--gpus", "2", "--steps", "3"])
+    out = capsys.readouterr().out.strip().splitlines()
+    assert rc == 0 and len(out) == 1                        # exactly ONE line on stdout: the JSON
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 2 and line["value"] == 3.0 and line["argv"] == ["--gpus", "2", "--steps", "3"]

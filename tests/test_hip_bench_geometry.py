@@ -108,7 +108,10 @@ def test_winograd_at_bench_grids(dev, n, h, c):
     u = ops.wino43_transform_weights(wt.permute(0, 2, 3, 1).contiguous().to(dev))
     xd, rd = x.permute(0, 2, 3, 1).contiguous().to(dev), r.permute(0, 2, 3, 1).contiguous().to(dev)
     tiles = (n * h * ((h + 3) // 4) + 127) // 128 * ((c + 63) // 64)
-    assert tiles > 256                                           # more than one round of CUs: the mixed launch
+    # 784 / 1568 (layer 1), 392 / 784 (layer 2): full rounds of the 256 CUs + a split-K tail + the fix-up in one call;
+    # 224 / 448 (layer 3) and 112 / 224 (layer 4): partial rounds, XCD remap over a ragged id range
+    assert tiles == {(56, 128): 784, (56, 256): 1568, (28, 128): 392, (28, 256): 784, (14, 128): 224, (14, 256): 448,
+                     (7, 128): 112, (7, 256): 224}[(h, n)]
     errs = {}
     for split in (1, 0):
         ops.set_tuning(ops.TUNE_WINO_SPLIT, split)
