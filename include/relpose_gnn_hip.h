@@ -75,6 +75,20 @@ int rpg_conv3x3_wino43_bn_act_nhwc_f32(const float* x, const float* u, const flo
                                        const float* residual, float* y, int n, int h, int w, int cin, int cout,
                                        int relu, void* stream);
 
+/* The whole ResNet stem in one kernel: conv1 (7x7, stride 2, pad 3, 3 -> 64 channels, no bias) + bn1 (eval) + ReLU +
+ * MaxPool2d(3, stride 2, padding 1) of torchvision's resnet34 (call site posenet.py:1037), straight from the NCHW input
+ * of posenet.py:1035 to the pooled NHWC tensor:  x_nchw [n][3][h][w] -> y [n][hp][wp][64],
+ * hc = (h - 1) / 2 + 1, hp = (hc - 1) / 2 + 1 (same for w).
+ *   wpack [74][2][64]  the weight operands of the kernel's 74 tap pairs with the BatchNorm scale folded in:
+ *                      wpack[kp][nf][l] = scale[ch] * W[ch][tap], ch = 32 nf + (l & 31), tap = tap_a[kp] for l < 32 and
+ *                      tap_b[kp] (0 if tap_b[kp].c == -1) for l >= 32, with the table of rpg_stem_pair_table
+ *                      (relpose-gnn_amd/params.py pack_stem_pairs builds it)
+ *   shift [64]         folded BatchNorm shift
+ * rpg_stem_pair_table: HOST arrays tap_a[74][3], tap_b[74][3] = (c, kh, kw) of the two taps of every pair.            */
+int rpg_stem_conv7x7s2_bn_relu_maxpool_f32(const float* x_nchw, const float* wpack, const float* shift, float* y_nhwc,
+                                           int n, int h, int w, void* stream);
+int rpg_stem_pair_table(int* tap_a, int* tap_b);
+
 /* nn.MaxPool2d(3, stride 2, padding 1), NHWC, c % 4 == 0. */
 int rpg_maxpool3x3s2_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, void* stream);
 
@@ -85,8 +99,9 @@ int rpg_global_avgpool_nhwc_f32(const float* x, float* y, int n, int hw, int c, 
  * (posenet.py:942-945, :1037).  `tensors` is a HOST array of device pointers laid out as
  * documented in relpose-gnn_amd/params.py (stem, then per block conv1/conv2/(downsample), each
  * as {w_ohwi, scale, shift, u_wino43}, then fc weight [feat][512] and bias).  u_wino43 may be NULL
- * (always for the stem, strided and 1x1 convolutions): that convolution then takes the direct
- * implicit-GEMM kernel.  `blocks[4]`/`planes[4]` HOST.
+ * (always for strided and 1x1 convolutions): that convolution then takes the direct implicit-GEMM
+ * kernel.  The stem's fourth slot holds the wpack of rpg_stem_conv7x7s2_bn_relu_maxpool_f32 (planes[0]
+ * == 64) or NULL (= re-layout + generic convolution + max-pool kernels).  `blocks[4]`/`planes[4]` HOST.
  * x_nchw [n][3][h][w] -> feat [n][feat_dim].                                                     */
 size_t rpg_resnet_workspace_bytes(int n, int h, int w, const int* planes);
 int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors, const int* blocks, const int* planes,
@@ -235,6 +250,7 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
                                      the 26-tensor table) | 0: reference formulation (gathered 3-source GEMMs) */
 #define RPG_TUNE_BF16_BK 6        /* K step of the bf16 convolution kernel: 32 (default) | 64 */
 #define RPG_TUNE_BF16_FAST 9      /* 1: interleaved buffer-load bf16 conv kernel where Cin % 64 == 0 (default) | 0: general kernel */
+#define RPG_TUNE_FUSED_STEM 10    /* 1: one-kernel stem (conv7x7 + BN + ReLU + max-pool) where its operands are given (default) | 0: three kernels */
 #define RPG_TUNE_WINO_SPLIT 8     /* 1: split-K tail + fix-up for the 8-wave Winograd kernel (default) | 0: whole tiles only */
 #define RPG_TUNE_FAST_LOADER 7    /* 1: buffer-load loaders + interleaved main loop where eligible (default) | 0: general loaders */
 #define RPG_TUNE_WINOGRAD 4       /* 0: always the direct kernel | 1: use u_wino43 where given, kernel by size (default) |

@@ -10,7 +10,8 @@ import os
 from typing import Optional, Sequence
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "librelpose_gnn_hip.so")
+# RPG_HIP_LIB: another build of the same library (A/B measurements of kernel changes); the product path is the in-tree one
+LIB_PATH = os.environ.get("RPG_HIP_LIB") or os.path.join(HERE, "lib", "librelpose_gnn_hip.so")
 
 RPG_OK, RPG_ERR_BAD_ARG, RPG_ERR_LAUNCH, RPG_ERR_WORKSPACE = 0, -1, -2, -3
 TIMER_NAMES = ("conv", "linear", "scatter", "attention", "conv_wino")
@@ -24,7 +25,7 @@ SYMBOLS = (
     "rpg_gnn_forward_f32", "rpg_timing_enable", "rpg_timing_read", "rpg_set_tuning", "rpg_knn_graph_f32", "rpg_wino43_transform_weights_f32",
     "rpg_conv3x3_wino43_bn_act_nhwc_f32", "rpg_conv2d_bn_act_nhwc_bf16", "rpg_resnet_bf16_workspace_bytes",
     "rpg_resnet_forward_bf16", "rpg_gnn_forward_bf16", "rpg_f32_to_bf16", "rpg_linear_bf16",
-    "rpg_release_scratch", "rpg_timing_read_ex",
+    "rpg_release_scratch", "rpg_timing_read_ex", "rpg_stem_conv7x7s2_bn_relu_maxpool_f32", "rpg_stem_pair_table",
 )
 
 
@@ -80,6 +81,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.rpg_timing_read_ex.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double)]
     lib.rpg_release_scratch.argtypes = []
+    lib.rpg_stem_conv7x7s2_bn_relu_maxpool_f32.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]
+    lib.rpg_stem_pair_table.argtypes = [C.POINTER(_i), C.POINTER(_i)]
     for name in SYMBOLS:
         getattr(lib, name)          # AttributeError here = the library does not export a declared symbol
 

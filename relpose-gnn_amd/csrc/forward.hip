@@ -9,6 +9,8 @@
 
 namespace rpg {
 int launch_relu_inplace(float* x, long n_floats, hipStream_t s);
+bool stem_pool_supported(int h, int w, int cout);
+int launch_stem_pool(const float* x_nchw, const float* wpack, const float* shift, float* out, int n, int h, int w, hipStream_t s);
 }
 
 namespace {
@@ -91,13 +93,19 @@ extern "C" int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors
 
     int rc;
     int ti = 0;
-    if ((rc = rpg_nchw3_to_nhwc4_f32(x_nchw, in4, n, h, w, stream)) != RPG_OK) return rc;
-    // stem: conv7x7/2 pad 3 (3 -> planes[0], input channels padded to 4 with zero weights) + BN + ReLU
-    if ((rc = rpg::launch_conv(in4, tensors[ti], tensors[ti + 1], tensors[ti + 2], nullptr, stem, n, h, w, 4,
-                               planes[0], 7, 7, 2, 3, 1, s, 3)) != RPG_OK)
-        return rc;
+    if (tensors[3] && rpg::stem_pool_supported(h, w, planes[0])) {
+        // the fused stem: NCHW input -> conv7x7/2 + BN + ReLU + maxpool3x3/2 -> pooled NHWC, one kernel (csrc/stem.hip);
+        // tensors[3] = its packed weight operands (BN scale folded in), tensors[2] = the BN shift
+        if ((rc = rpg::launch_stem_pool(x_nchw, tensors[3], tensors[2], buf[0], n, h, w, s)) != RPG_OK) return rc;
+    } else {
+        if ((rc = rpg_nchw3_to_nhwc4_f32(x_nchw, in4, n, h, w, stream)) != RPG_OK) return rc;
+        // stem: conv7x7/2 pad 3 (3 -> planes[0], input channels padded to 4 with zero weights) + BN + ReLU
+        if ((rc = rpg::launch_conv(in4, tensors[ti], tensors[ti + 1], tensors[ti + 2], nullptr, stem, n, h, w, 4,
+                                   planes[0], 7, 7, 2, 3, 1, s, 3)) != RPG_OK)
+            return rc;
+        if ((rc = rpg_maxpool3x3s2_nhwc_f32(stem, buf[0], n, p.h1, p.w1, planes[0], stream)) != RPG_OK) return rc;
+    }
     ti += 4;
-    if ((rc = rpg_maxpool3x3s2_nhwc_f32(stem, buf[0], n, p.h1, p.w1, planes[0], stream)) != RPG_OK) return rc;
 
     int cur = 0, hh = p.h2, ww = p.w2;
     cin = planes[0];

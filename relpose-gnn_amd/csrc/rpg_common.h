@@ -72,6 +72,7 @@ bool wino_enabled();
 // addressable, and large enough that the un-split K loop is not latency-bound)
 bool wino_pays(int n, int h, int w, int cin, int cout);
 void wino_set(int on);
+void stem_pool_set(int on);
 void wino_split_set(int on);
 void bf16_set_fast(int on);
 int launch_f32_to_bf16(const float* src, int ld_src, void* dst, int ld_dst, int col_off, long rows, int cols, hipStream_t s);

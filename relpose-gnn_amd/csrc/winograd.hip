@@ -57,13 +57,21 @@ __device__ __forceinline__ float4 sub(const float4& x, const float4& y) {
 // Epilogue of one wave: output transform of its 6 accumulators (lane-local: the MFMA C layout puts the same (tile,
 // cout) element of all 6 products in the same lane), then an LDS transpose to 16-byte row segments and the fused
 // BatchNorm / residual / ReLU / store, two of the four pixel columns at a time.  mw0 = first tile of the wave's 32,
-// nw0 = first output channel of its 32; slab = 64 x 36 floats of LDS private to the wave.
-// Nothing overlaps an epilogue when a CU holds one workgroup, so it is written for latency: the 16 row addresses of a
-// lane are computed once with ONE integer division (the rest is incremental), residual reads and output stores are raw
-// buffer accesses based at the wave's first image row (invalid rows / columns / channels carry an out-of-range offset:
-// reads return zero, stores are dropped), hence branch-free, and the 8 residual reads of a half are all in flight
-// before its transform starts instead of one dependent round trip per row.
+// nw0 = first output channel of its 32 (both WAVE-UNIFORM and passed as scalars: the caller derives them from
+// readfirstlane(wave id), which keeps the two buffer resources in SGPRs -- with a lane-derived wave id the compiler
+// wrapped every one of the 32 buffer accesses in a waterfall loop); slab = 64 x 36 floats of LDS private to the wave.
+// Nothing overlaps an epilogue when a CU holds one workgroup, so it is written for latency and instruction count (it is
+// issue-bound: ~1500 instructions per wave before this version):
+//   * the 16 row addresses of a lane come from ONE integer division (the rest is incremental);
+//   * residual reads and output stores are raw buffer accesses based at the wave's first image row (invalid rows /
+//     columns / channels carry an out-of-range offset: reads return zero, stores are dropped), hence branch-free;
+//   * all 16 residual reads (both halves) are issued before the output transform: one exposed round trip, hidden
+//     behind the transform's arithmetic, instead of one per half;
+//   * the output transform works on register PAIRS (elements e, e+1 of an accumulator = tiles t, t+1 of the same
+//     channel) with packed f32 instructions and shares the sums / differences m1+-m2, m3+-m4 between the four outputs:
+//     11 packed instructions per pair instead of ~30 scalar ones.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void wino43_epilogue(const f32x16 (&acc)[P], float* slab, int lane, int mw0, int nw0, int M,
                                                 int Tw, int W, int Cout, const Epi& ep) {
     constexpr int EP = 32 + 4;                              // slab pitch: 32 channels + pad
@@ -97,41 +105,56 @@ __device__ __forceinline__ void wino43_epilogue(const f32x16 (&acc)[P], float* s
         tw += step_tw;
         if (tw >= Tw) { tw -= Tw; ++trel; }
     }
+    float4 rs[2][8];
+    if (ep.residual) {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        float4 rs[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) rs[it] = f4zero();
-        if (ep.residual) {
+        for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int it = 0; it < 8; ++it)
-                rs[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, voff[half][it], 0, 0));
-        }
+                rs[half][it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, voff[half][it], 0, 0));
+    } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e];
-            float ya, yb;
-            if (half == 0) {
-                ya = acc[0][e] + m1 + m2 + m3 + m4;                     // y0
-                yb = (m1 - m2) + 2.f * (m3 - m4);                       // y1
-            } else {
-                ya = (m1 + m2) + 4.f * (m3 + m4);                       // y2
-                yb = (m1 - m2) + 8.f * (m3 - m4) + acc[5][e];           // y3
-            }
-            const int trow = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);  // tile within the wave's 32
-            slab[(2 * trow) * EP + (lane & 31)] = ya;
-            slab[(2 * trow + 1) * EP + (lane & 31)] = yb;
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) rs[half][it] = f4zero();
+    }
+    const float floor_v = ep.relu ? 0.f : -INFINITY;        // ReLU without a branch per store
+    // output transform y = AT m (AT of F(4,3), points 0, +-1, +-2, inf) on pairs of elements
+    f32x2 y[4][8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = 2 * q;
+        const f32x2 m0 = {acc[0][e], acc[0][e + 1]}, m1 = {acc[1][e], acc[1][e + 1]}, m2 = {acc[2][e], acc[2][e + 1]};
+        const f32x2 m3 = {acc[3][e], acc[3][e + 1]}, m4 = {acc[4][e], acc[4][e + 1]}, m5 = {acc[5][e], acc[5][e + 1]};
+        const f32x2 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+        const f32x2 u = d34 + d34;                          // 2 (m3 - m4), exact
+        y[0][q] = (m0 + s12) + s34;                         // y0 = m0 + m1 + m2 + m3 + m4
+        y[1][q] = d12 + u;                                  // y1 = (m1 - m2) + 2 (m3 - m4)
+        y[2][q] = s12 + 4.f * s34;                          // y2 = (m1 + m2) + 4 (m3 + m4)
+        y[3][q] = (d12 + 4.f * u) + m5;                     // y3 = (m1 - m2) + 8 (m3 - m4) + m5
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = 2 * q;
+            const int trow = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);  // tile within the wave's 32 (element e; e+1: +1)
+            float* sp = slab + (2 * trow) * EP + (lane & 31);
+            sp[0] = y[2 * half][q].x;
+            sp[EP] = y[2 * half + 1][q].x;
+            sp[2 * EP] = y[2 * half][q].y;
+            sp[3 * EP] = y[2 * half + 1][q].y;
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int prow = pr + 8 * it;                               // 0..63 = (tile, pixel-in-half)
             const float4 v = *reinterpret_cast<const float4*>(&slab[prow * EP + 4 * c4]);
-            float4 y;
-            y.x = v.x * sc.x + sh.x + rs[it].x; y.y = v.y * sc.y + sh.y + rs[it].y;
-            y.z = v.z * sc.z + sh.z + rs[it].z; y.w = v.w * sc.w + sh.w + rs[it].w;
-            if (ep.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, voff[half][it], 0, 0);
+            const f32x2 r0 = {rs[half][it].x, rs[half][it].y}, r1 = {rs[half][it].z, rs[half][it].w};
+            f32x2 o0 = f32x2{v.x, v.y} * f32x2{sc.x, sc.y} + f32x2{sh.x, sh.y} + r0;
+            f32x2 o1 = f32x2{v.z, v.w} * f32x2{sc.z, sc.w} + f32x2{sh.z, sh.w} + r1;
+            const float4 yv = make_float4(fmaxf(o0.x, floor_v), fmaxf(o0.y, floor_v), fmaxf(o1.x, floor_v), fmaxf(o1.y, floor_v));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yv), ro, voff[half][it], 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -326,7 +349,8 @@ __global__ __launch_bounds__(NT, 2) void wino43_conv_kernel(const float* __restr
     }
     __syncthreads();                     // LDS becomes the epilogue slabs
 
-    wino43_epilogue(acc, lds + wave * (64 * 36), lane, m0 + wm * 32, n0 + wn * 32, M, Tw, W, Cout, ep);
+    const int ws = __builtin_amdgcn_readfirstlane(wave);       // wave-uniform by construction: scalar addressing below
+    wino43_epilogue(acc, lds + ws * (64 * 36), lane, m0 + (ws >> 1) * 32, n0 + (ws & 1) * 32, M, Tw, W, Cout, ep);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -398,13 +422,19 @@ __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restri
                                                           Split sp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int K = 3 * Cin;
-    const int kpr = (Cin + BK - 1) / BK;               // K steps per kernel row
-    int tile, kb = 0, nk = 3 * kpr;                    // this workgroup's tile and K-step range [kb, nk)
+    // K is walked CHANNEL-BLOCK major, kernel row minor: step t covers channels 16 (t / 3) .. + 15 of kernel row t % 3.
+    // The three kernel rows of a channel block read the SAME input rows (tile row r reads image rows r-1, r, r+1), so
+    // with this order an input row's 64-byte segment is fetched from HBM once and re-read from L2 / L1 within three
+    // consecutive K steps.  (Kernel-row major, the order of round 1, re-read it after Cin/16 steps, by when the resident
+    // workgroups of an XCD (32 x 160 KB at layer 1) had pushed it out of the 4-MB L2: PMC showed 2.0x the algorithmic
+    // read traffic, FETCH_SIZE calibrated with tools/probes/fetch_calib_probe.hip.)
+    const int kpr = (Cin + BK - 1) / BK;               // channel blocks = K steps per kernel row
+    int tile, kb = 0, nk = 3 * kpr;                    // this workgroup's tile and K-step range [kb, nk), multiples of 3
     if constexpr (SPLIT) {
         const int tt = blockIdx.x / sp.parts, part = blockIdx.x - tt * sp.parts;
         tile = sp.tile_base + tt;
-        kb = part * nk / sp.parts;
-        nk = (part + 1) * nk / sp.parts;
+        kb = 3 * (part * kpr / sp.parts);
+        nk = 3 * ((part + 1) * kpr / sp.parts);
     } else {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r8 = nwg & 7;
@@ -425,7 +455,7 @@ __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restri
         const_cast<float*>(x + n_first * img_floats) - (size_t)W * Cin, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, 0x7fffffff, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    unsigned va[P], va_eff[P];
+    unsigned va[P], va3[3][P];            // va3[kh]: offsets of the six pixels for kernel row kh, OOB where the row is outside
     unsigned rowbits = 0;                 // bit kh set <=> image row ho-1+kh exists (and the tile itself does)
     {
         const int m = m0 + row;
@@ -447,32 +477,39 @@ __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restri
     const unsigned ustride_b = (unsigned)Cout * K * 4u;
     const unsigned vb = n0 + brow < Cout ? 4u * (unsigned)((n0 + brow) * K + 4 * slot) + 3u * bhalf * ustride_b : OOB;
     unsigned vb_eff;
-    int f_kt = kb, f_kh = kb / kpr, f_c0 = (kb % kpr) * BK;     // the K step the next fetches load (wave-uniform)
-    auto refresh = [&]() {                // effective offsets of K step f_kt: row border, channel tail, past the end
-        asm volatile("" ::: "memory");    // keeps this a (rarely taken) branch: if-converted it is 11 VALU per K step
+    int f_kt = kb, f_c0 = (kb / 3) * BK;  // the K step / channel block the next fetches load (wave-uniform)
+    const unsigned row_b = 4u * (unsigned)(W * Cin), krow_b = 4u * (unsigned)Cin;       // bytes per image row / per kernel row of U
+    auto refresh = [&]() {                // effective offsets of channel block f_c0: row borders, channel tail, past the end
+        asm volatile("" ::: "memory");    // keeps this a (rarely taken) branch
         const bool cv = f_kt < nk && f_c0 + 4 * slot < Cin;
-        const bool rv = cv && ((rowbits >> f_kh) & 1u);
 #pragma unroll
-        for (int j = 0; j < P; ++j) va_eff[j] = rv ? va[j] : OOB;
+        for (int kh = 0; kh < 3; ++kh) {
+            const bool rv = cv && ((rowbits >> kh) & 1u);
+#pragma unroll
+            for (int j = 0; j < P; ++j) va3[kh][j] = rv ? va[j] : OOB;
+        }
         vb_eff = cv ? vb : OOB;
     };
     refresh();
 
     float4 d[P], ub[3];
-    auto fetch_one = [&](int i) {         // i = 0..8: pixels 0..5, then this thread's 3 U positions
+    // fetch_one(i, kh), i = 0..8: pixels 0..5 of kernel row kh (compile-time), then this thread's 3 U positions
+    auto fetch_one = [&](int i, int kh) {
         if (i < P) {
-            const unsigned sa = 4u * (unsigned)(f_kh * W * Cin + f_c0);
-            d[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, va_eff[i], sa, 0));
+            const unsigned sa = (unsigned)kh * row_b + 4u * (unsigned)f_c0;
+            d[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, va3[kh][i], sa, 0));
         } else {
-            const unsigned sb = 4u * (unsigned)(f_kh * Cin + f_c0) + (unsigned)(i - P) * ustride_b;
+            const unsigned sb = (unsigned)kh * krow_b + 4u * (unsigned)f_c0 + (unsigned)(i - P) * ustride_b;
             ub[i - P] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, vb_eff, sb, 0));
         }
     };
-    auto fetch_next = [&]() {
+    // after the fetches of kernel row kh: next step; a new channel block starts after kernel row 2
+    auto fetch_next = [&](int kh) {
         ++f_kt;
-        f_c0 += BK;
-        if (f_c0 >= Cin) { f_c0 = 0; ++f_kh; }
-        if (f_c0 == 0 || f_c0 + BK > Cin || f_kt >= nk) refresh();        // rare: 3 + 2 times for Cin % 16 == 0
+        if (kh == 2) {
+            f_c0 += BK;
+            if (f_c0 + BK > Cin || f_kt >= nk) refresh();       // rare: channel tail (Cin % 16 != 0) and past the end
+        }
     };
 
     // stage_one(p, img), p = 0..8: piece p of the K step held in d / ub -> LDS image img (float offset).  p < 6: the
@@ -517,11 +554,12 @@ __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restri
         if (i & 1) fb[set][i >> 1] = *reinterpret_cast<const float4*>(&lds[img + xi * BN * LD + (b_off ^ kb)]);
         else       fa[set][i >> 1] = *reinterpret_cast<const float4*>(&lds[img + xi * BMT8 * LD + (a_off ^ kb)]);
     };
-    // one K step on image `cur` (compile-time float offset), staging step kt+1 into `nxt`, fetching step kt+2:
+    // one K step on image `cur` (compile-time float offset), staging step kt+1 into `nxt`, fetching step kt+2 (kernel
+    // row khf, compile time):
     //   groups 0-5, MFMAs 0-3: the 4 operand reads of the next group (group 5: of the next K step's group 0, from nxt)
     //   groups 0-2, MFMAs 4-7: stage pieces 0..8 -> nxt        groups 3-5, MFMAs 4-7: buffer loads 0..8
     //   barrier after group 4: every wave has written nxt and issued its last reads of cur
-    auto kstep = [&](int cur, int nxt) {
+    auto kstep = [&](int cur, int nxt, int khf) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
@@ -539,7 +577,7 @@ __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restri
                     const int s = 4 * (g % 3) + (i - 4);              // 0..11, pieces 0..8 used
                     if (s < 9) {
                         if (g < 3) stage_one(s, nxt);
-                        else fetch_one(s);
+                        else fetch_one(s, khf);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -549,32 +587,42 @@ __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restri
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        fetch_next();
+        fetch_next(khf);
     };
 
+    // local step s = kt - kb (kb is a multiple of 3) runs kernel row s % 3 on image s % 2 and fetches kernel row (s+2) % 3
 #pragma unroll
-    for (int i = 0; i < 9; ++i) fetch_one(i);
-    fetch_next();
+    for (int i = 0; i < 9; ++i) fetch_one(i, 0);
+    fetch_next(0);
 #pragma unroll
     for (int p = 0; p < 9; ++p) stage_one(p, 0);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) fetch_one(i);
-    fetch_next();
+    for (int i = 0; i < 9; ++i) fetch_one(i, 1);
+    fetch_next(1);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) frag_one(0, 0, i, 0);
     int kt = kb;
-    for (; kt + 1 < nk; kt += 2) {
-        kstep(0, IMG8_FLOATS);
-        kstep(IMG8_FLOATS, 0);
+    for (; kt + 5 < nk; kt += 6) {
+        kstep(0, IMG8_FLOATS, 2);
+        kstep(IMG8_FLOATS, 0, 0);
+        kstep(0, IMG8_FLOATS, 1);
+        kstep(IMG8_FLOATS, 0, 2);
+        kstep(0, IMG8_FLOATS, 0);
+        kstep(IMG8_FLOATS, 0, 1);
     }
-    if (kt < nk) kstep(0, IMG8_FLOATS);
+    if (kt < nk) {                       // (nk - kb) % 6 == 3: three more steps
+        kstep(0, IMG8_FLOATS, 2);
+        kstep(IMG8_FLOATS, 0, 0);
+        kstep(0, IMG8_FLOATS, 1);
+    }
     __syncthreads();                     // LDS becomes the epilogue slabs
+    const int ws = __builtin_amdgcn_readfirstlane(wave);       // wave-uniform by construction: scalar addressing below
     if constexpr (SPLIT)
-        wino43_epilogue_partial(acc, lds + wave * (64 * 36), lane, wm * 32, wn * 32,
+        wino43_epilogue_partial(acc, lds + ws * (64 * 36), lane, (ws >> 1) * 32, (ws & 1) * 32,
                                 sp.partial + (size_t)blockIdx.x * (BMT8 * 4 * BN));
     else
-        wino43_epilogue(acc, lds + wave * (64 * 36), lane, m0 + wm * 32, n0 + wn * 32, M, Tw, W, Cout, ep);
+        wino43_epilogue(acc, lds + ws * (64 * 36), lane, m0 + (ws >> 1) * 32, n0 + (ws & 1) * 32, M, Tw, W, Cout, ep);
 }
 
 // Sums the `parts` partial slabs of tail tile blockIdx.x / 32 in k order and applies BatchNorm / residual / ReLU.

@@ -143,6 +143,20 @@ def linear_bf16(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     return out
 
 
+def stem_conv_bn_relu_maxpool(x_nchw: torch.Tensor, wpack: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+    """conv7x7/2 (3 -> 64) + BN + ReLU + maxpool3x3/2 in one kernel: [N,3,H,W] -> pooled NHWC [N,Hp,Wp,64]; wpack from
+    params.pack_stem_pairs (BatchNorm scale folded in), shift [64]."""
+    x, wpack, shift = _req(x_nchw, "x_nchw"), _req(wpack, "wpack"), _req(shift, "shift")
+    n, c, h, w = x.shape
+    if c != 3 or tuple(wpack.shape) != (74, 2, 64) or shift.numel() != 64:
+        raise ValueError("expected x [N,3,H,W], wpack [74,2,64], shift [64]")
+    hc, wc = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty((n, (hc - 1) // 2 + 1, (wc - 1) // 2 + 1, 64), dtype=torch.float32, device=x.device)
+    L.check(L.lib().rpg_stem_conv7x7s2_bn_relu_maxpool_f32(_p(x), _p(wpack), _p(shift), _p(y), n, h, w, _stream()),
+            "stem_conv_bn_relu_maxpool")
+    return y
+
+
 def maxpool3x3s2_nhwc(x: torch.Tensor) -> torch.Tensor:
     x = _req(x, "x")
     n, h, w, c = x.shape
@@ -266,7 +280,7 @@ def release_scratch() -> None:
     L.check(L.lib().rpg_release_scratch(), "release_scratch")
 
 
-TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST, TUNE_FUSED_STEM = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 
 def set_tuning(key: int, value: int) -> None:

@@ -10,6 +10,7 @@ encoder (``rpg_resnet_forward_f32`` tensor order)
         scale   [Cout] = gamma / sqrt(running_var + eps)          (eval-mode BatchNorm folded to an affine
         shift   [Cout] = beta - running_mean * scale               epilogue; the conv weights are untouched)
         u       [6][Cout][3][Cin]     = Winograd F(4,3) weights of a 3x3 stride-1 convolution, or None
+                                        (stem: wpack [74][2][64] of the fused stem kernel, see pack_stem_pairs)
     then fc.weight [feat][512], fc.bias [feat]
 
 GNN (``rpg_gnn_forward_f32`` tensor order, 22 tensors + 4 optional split matrices, see pack_gnn)
@@ -44,6 +45,38 @@ def _ohwi(w: torch.Tensor, pad_cin_to: int = 0) -> torch.Tensor:
     return w.contiguous()
 
 
+def stem_pair_table() -> Tuple[List[Tuple[int, int, int]], List[Optional[Tuple[int, int, int]]]]:
+    """The 74 tap pairs (c, kh, kw) of the fused stem kernel (csrc/stem.hip pair_off / pair_class; a host test compares this
+    with rpg_stem_pair_table): 63 pairs of neighbouring columns (kw = 0|1, 2|3, 4|5 of every (c, kh)), 9 pairs of
+    neighbouring rows in the last column (kh = 0|1, 2|3, 4|5 at kw = 6), the pair (c = 0 | 1) at (6, 6), and (2, 6, 6) alone."""
+    a: List[Tuple[int, int, int]] = []
+    b: List[Optional[Tuple[int, int, int]]] = []
+    for c in range(3):
+        for kh in range(7):
+            for q in range(3):
+                a.append((c, kh, 2 * q)); b.append((c, kh, 2 * q + 1))
+    for c in range(3):
+        for q in range(3):
+            a.append((c, 2 * q, 6)); b.append((c, 2 * q + 1, 6))
+    a.append((0, 6, 6)); b.append((1, 6, 6))
+    a.append((2, 6, 6)); b.append(None)
+    return a, b
+
+
+def pack_stem_pairs(w_oihw: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """conv1.weight [64][3][7][7] and the folded BatchNorm scale [64] -> wpack [74][2][64] of
+    rpg_stem_conv7x7s2_bn_relu_maxpool_f32: element [kp][nf][l] = scale[ch] * W[ch][tap], ch = 32 nf + (l & 31), tap = first
+    (l < 32) or second (l >= 32) tap of pair kp (0 for the missing partner of the last pair)."""
+    if tuple(w_oihw.shape) != (64, 3, 7, 7):
+        raise ValueError("the fused stem kernel is for Conv2d(3, 64, 7)")
+    w = w_oihw.float() * scale.float().view(64, 1, 1, 1)
+    a, b = stem_pair_table()
+    wa = torch.stack([w[:, c, kh, kw] for c, kh, kw in a])                                   # [74][64]
+    wb = torch.stack([w[:, t[0], t[1], t[2]] if t is not None else torch.zeros_like(w[:, 0, 0, 0]) for t in b])
+    out = torch.stack([wa.view(74, 2, 32), wb.view(74, 2, 32)], dim=2)                       # [74][nf][half][32]
+    return out.reshape(74, 2, 64).contiguous()
+
+
 def resnet_structure(sd: Dict[str, torch.Tensor], prefix: str) -> Tuple[List[int], List[int]]:
     """(blocks per layer, planes per layer) read off the state-dict keys."""
     blocks, planes = [], []
@@ -71,7 +104,9 @@ def pack_resnet(sd: Dict[str, torch.Tensor], prefix: str = "feature_extractor.",
     w = sd[prefix + "conv1.weight"]
     if tuple(w.shape[1:]) != (3, 7, 7) or w.shape[0] != planes[0]:
         raise ValueError("stem must be Conv2d(3, planes[0], 7, stride 2, pad 3)")
-    t += [_ohwi(w, pad_cin_to=4), *_bn_affine(sd, prefix + "bn1."), None]
+    sc1, sh1 = _bn_affine(sd, prefix + "bn1.")
+    # fourth slot: operands of the fused conv + BN + ReLU + max-pool stem kernel (64-channel stems only)
+    t += [_ohwi(w, pad_cin_to=4), sc1, sh1, pack_stem_pairs(w, sc1) if w.shape[0] == 64 else None]
     cin = planes[0]
     for li, (nb, c) in enumerate(zip(blocks, planes), start=1):
         for b in range(nb):

@@ -75,6 +75,24 @@ def test_conv_transpose_detecting(dev):
     assert rel_err(y.cpu().permute(0, 3, 1, 2), ref) < 1e-6
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 224, 224), (1, 256, 341), (3, 64, 64), (2, 37, 53), (1, 7, 9), (1, 450, 600), (5, 32, 40)])
+def test_fused_stem_conv_bn_relu_maxpool(dev, n, h, w):
+    """rpg_stem_conv7x7s2_bn_relu_maxpool_f32 vs conv2d(7x7, s2, p3) -> BN affine -> ReLU -> max_pool2d(3, 2, 1) (the
+    torchvision stem reached from posenet.py:1037): 224x224 (one column tile of 56), the 256x341 evaluation shape (two
+    column tiles), odd / tiny sizes (ragged tiles, all-border tiles) and a wide image (three column tiles)."""
+    from relpose_gnn_amd import ops
+    from relpose_gnn_amd.params import pack_stem_pairs
+    x = _rand(n, 3, h, w, seed=h)
+    wt = _rand(64, 3, 7, 7, seed=2, scale=(2.0 / 147) ** 0.5)
+    g = torch.Generator().manual_seed(3)
+    scale = (torch.rand(64, generator=g) + 0.5) * torch.where(torch.rand(64, generator=g) < 0.15, -1.0, 1.0)   # some negative gammas
+    shift = _rand(64, seed=4, scale=0.3)
+    ref = F.max_pool2d(F.relu(F.conv2d(x, wt, None, stride=2, padding=3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)), 3, 2, 1)
+    y = ops.stem_conv_bn_relu_maxpool(x.to(dev), pack_stem_pairs(wt, scale).to(dev), shift.to(dev))
+    assert y.shape == (n, ref.shape[2], ref.shape[3], 64)
+    assert rel_err(y.cpu().permute(0, 3, 1, 2), ref) < 1e-5
+
+
 def test_maxpool_and_avgpool(dev):
     from relpose_gnn_amd import ops
     x = _rand(3, 16, 13, 18, seed=7)

@@ -167,3 +167,25 @@ def test_stream_partition_from_pyg_batch_tables():
     assert m._partition(pyg2, n, e) == [(0, 24, 0, 168), (24, 48, 168, 336)]
     assert m._partition(types.SimpleNamespace(x=ref.x[:8], edge_index=ref.edge_index[:, :56], batch=ref.batch[:8],
                                               num_graphs=1), 8, 56) is None
+
+
+def test_stem_pair_table_matches_the_kernel():
+    """params.stem_pair_table (what pack_stem_pairs packs by) == rpg_stem_pair_table (what csrc/stem.hip reads by)."""
+    import ctypes as C
+    from relpose_gnn_amd import _lib
+    from relpose_gnn_amd.params import pack_stem_pairs, stem_pair_table
+    ta, tb = (C.c_int * 222)(), (C.c_int * 222)()
+    assert _lib.lib().rpg_stem_pair_table(ta, tb) == 0
+    a, b = stem_pair_table()
+    assert len(a) == len(b) == 74
+    assert [tuple(ta[3 * i: 3 * i + 3]) for i in range(74)] == a
+    assert [None if tb[3 * i] < 0 else tuple(tb[3 * i: 3 * i + 3]) for i in range(74)] == b
+    taps = sorted(a + [t for t in b if t is not None])
+    assert taps == sorted((c, kh, kw) for c in range(3) for kh in range(7) for kw in range(7))      # every tap exactly once
+    w = torch.arange(64 * 147, dtype=torch.float32).view(64, 3, 7, 7)
+    sc = torch.full((64,), 2.0)
+    wp = pack_stem_pairs(w, sc)
+    assert wp.shape == (74, 2, 64)
+    assert float(wp[5, 1, 7]) == 2.0 * float(w[39, a[5][0], a[5][1], a[5][2]])                      # first tap, channel 32 + 7
+    assert float(wp[5, 1, 32 + 7]) == 2.0 * float(w[39, b[5][0], b[5][1], b[5][2]])                # second tap
+    assert float(wp[73, 0, 40]) == 0.0                                                              # the missing partner
