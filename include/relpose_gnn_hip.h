@@ -250,11 +250,15 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
                                      the 26-tensor table) | 0: reference formulation (gathered 3-source GEMMs) */
 #define RPG_TUNE_BF16_BK 6        /* K step of the bf16 convolution kernel: 32 (default) | 64 */
 #define RPG_TUNE_BF16_FAST 9      /* 1: interleaved buffer-load bf16 conv kernel where Cin % 64 == 0 (default) | 0: general kernel */
+#define RPG_TUNE_WAVES8 11        /* 1: 8-wave workgroups (two waves per SIMD) for the 128x128 / 128x64 tiles of the f32 tile engine where
+                                     the buffer-load path applies (default) | 0: always 4-wave workgroups */
 #define RPG_TUNE_FUSED_STEM 10    /* 1: one-kernel stem (conv7x7 + BN + ReLU + max-pool) where its operands are given (default) | 0: three kernels */
 #define RPG_TUNE_WINO_SPLIT 8     /* 1: split-K tail + fix-up for the 8-wave Winograd kernel (default) | 0: whole tiles only */
 #define RPG_TUNE_FAST_LOADER 7    /* 1: buffer-load loaders + interleaved main loop where eligible (default) | 0: general loaders */
 #define RPG_TUNE_WINOGRAD 4       /* 0: always the direct kernel | 1: use u_wino43 where given, kernel by size (default) |
-                                     2 / 3: as 1 but always the 4-wave (64 tiles) / 8-wave (128 tiles) Winograd kernel */
+                                     2 / 3 / 4: as 1 but always the 4-wave single-image / 8-wave / 4-wave short-K Winograd kernel */
+#define RPG_TUNE_WINO_SHORT 12    /* auto mode: convolutions with at most this many input channels on chip-filling grids take the
+                                     short-K kernel (two 4-wave workgroups per CU, K step 8); default 0 = never (measured: no gain) */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -283,6 +283,53 @@ def test_tile_engine_variants(dev, bk, epi, tile, streamk):
         ops.set_tuning(ops.TUNE_STREAMK, 1)
 
 
+@pytest.mark.parametrize("tile", [0, 3])
+@pytest.mark.parametrize("streamk", [0, 1])
+def test_tile_engine_eight_wave_workgroups(dev, tile, streamk):
+    """The 8-wave instantiation of the tile engine (two waves per SIMD; 128x128 and 128x64 tiles, K step 32, buffer loaders)
+    against torch and against the 4-wave one (RPG_TUNE_WAVES8 = 0): a strided 3x3 convolution with residual whose tile count
+    leaves a stream-K remainder, a 1x1/2 convolution, and the gathered Linears of the GNN (two gathered residual rows in the
+    epilogue, K = 2048 and K = 256) at M = 1792 / 256 rows."""
+    from relpose_gnn_amd import ops
+    try:
+        ops.set_tuning(ops.TUNE_TILE, tile)
+        ops.set_tuning(ops.TUNE_STREAMK, streamk)
+        for ci, (n, h, w, cin, cout, k, st, pad, res) in enumerate([(9, 28, 28, 128, 256, 3, 2, 1, True), (7, 30, 22, 64, 160, 1, 2, 0, False)]):
+            x = _rand(n, cin, h, w, seed=140 + ci)
+            wt = _rand(cout, cin, k, k, seed=150 + ci, scale=(2.0 / (cin * k * k)) ** 0.5)
+            scale = torch.rand(cout, generator=torch.Generator().manual_seed(160 + ci)) + 0.5
+            shift = _rand(cout, seed=170 + ci, scale=0.1)
+            ref = F.conv2d(x, wt, None, stride=st, padding=pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+            r = _rand(*ref.shape, seed=180 + ci) if res else None
+            ref = F.relu(ref + r if res else ref)
+            args = (x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev), scale.to(dev),
+                    shift.to(dev), None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev))
+            y8 = ops.conv2d_bn_act_nhwc(*args, stride=st, pad=pad, relu=True)
+            ops.set_tuning(ops.TUNE_WAVES8, 0)
+            y4 = ops.conv2d_bn_act_nhwc(*args, stride=st, pad=pad, relu=True)
+            ops.set_tuning(ops.TUNE_WAVES8, 1)
+            assert rel_err(y8.cpu().permute(0, 3, 1, 2), ref) < TOL and rel_err(y8, y4) < TOL, ci
+        g0 = torch.Generator().manual_seed(9)
+        for m, widths, n_out in [(1792, (2048,), 768), (1792, (256,), 2048), (256, (2048, 2048), 512), (300, (64, 32, 160), 132)]:
+            srcs, cat = [], []
+            for i, wd in enumerate(widths):
+                a = _rand(m, wd, seed=110 + i)
+                srcs.append((a.to(dev), None))
+                cat.append(a)
+            kk = sum(widths)
+            wl, bias, res = _rand(n_out, kk, seed=120, scale=kk ** -0.5), _rand(n_out, seed=121), _rand(m, n_out, seed=122)
+            ref = F.relu(F.linear(torch.cat(cat, 1), wl, bias) + res)
+            out8 = ops.linear_gather(srcs, wl.to(dev), bias.to(dev), m, res.to(dev), True)
+            ops.set_tuning(ops.TUNE_WAVES8, 0)
+            out4 = ops.linear_gather(srcs, wl.to(dev), bias.to(dev), m, res.to(dev), True)
+            ops.set_tuning(ops.TUNE_WAVES8, 1)
+            assert rel_err(out8.cpu(), ref) < TOL and rel_err(out8, out4) < TOL, (m, widths, n_out)
+    finally:
+        ops.set_tuning(ops.TUNE_WAVES8, 1)
+        ops.set_tuning(ops.TUNE_TILE, -1)
+        ops.set_tuning(ops.TUNE_STREAMK, 1)
+
+
 @pytest.mark.parametrize("bk", [16, 32])
 @pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3])
 @pytest.mark.parametrize("streamk", [0, 1])
@@ -359,7 +406,7 @@ def test_knn_graph(dev, sizes, k, d):
     (2, 256 // 8, 341 // 8 + 1, 128, 128, True, True),   # odd width from the 256x341 evaluation shape (32x43)
     (40, 12, 9, 20, 68, True, True),       # many images per 128-tile workgroup, channel tail (Cin % 16 = 4), odd K-step count
 ])
-@pytest.mark.parametrize("kernel", [2, 3], ids=["wave4", "wave8"])
+@pytest.mark.parametrize("kernel", [2, 3, 4], ids=["wave4", "wave8", "short"])
 def test_conv3x3_winograd(dev, n, h, w, cin, cout, res, relu, kernel):
     """1-D Winograd F(4,3) convolution vs F.conv2d; tolerance 2e-5 (the transforms cost ~2.5x the rounding error of
     the direct kernel per layer: measured in tools, still 5x below the per-op bar used elsewhere x 2)."""

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-end profile collection on the GPU box (run from the repo root):  tools/collect_profiles.sh <tag>
+# Profile collection on the GPU box (run from the repo root):  tools/collect_profiles.sh <tag>
 # 1. rocprofv3 --kernel-trace --stats of the default bench command and of the single-stream variant
-# 2. PMC passes (counters only) for HBM traffic of the single-stream variant: FETCH_SIZE and WRITE_SIZE separately
+# 2. PMC passes (counters only, no other tracing) of the single-stream variant: FETCH_SIZE, WRITE_SIZE, MFMA occupancy
 set -u
 TAG=${1:-final}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -16,6 +16,16 @@ P="$R/bench.py --steps 3 --warmup 1 --cpu-baseline-seconds 0 --streams 1 --no-ke
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o p -- python3 $P > "$OUT/pmc_fetch.log" 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o p -- python3 $P > "$OUT/pmc_write.log" 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_F32 --output-format csv -d "$OUT/pmc_mfma" -o p -- python3 $P > "$OUT/pmc_mfma.log" 2>&1
-# keep the merge small: drop the per-dispatch counter rows once summarised is not possible here; just list
-du -sh "$OUT"/* | tail -12
-grep -h '"metric"' "$OUT"/trace_default.log "$OUT"/trace_1stream.log | cut -c1-200
+cd "$R"
+python3 tools/pmc_traffic.py "$OUT" "wino43_conv8_kernel<false>" "$OUT/pmc_wino43.json" 32 > "$OUT/pmc_wino43.txt" 2>&1
+python3 tools/pmc_summary.py "$OUT" wino43 > "$OUT/pmc_wino43_summary.txt" 2>&1
+python3 tools/pmc_summary.py "$OUT" stem_pool > "$OUT/pmc_stem_summary.txt" 2>&1
+for t in trace_default trace_1stream; do
+  f=$(ls "$OUT/$t"/*kernel_stats.csv 2>/dev/null | head -1)
+  [ -n "$f" ] && python3 tools/rocprof_summary.py "$f" "$OUT/kernel_stats_$t.txt" > /dev/null
+done
+# the per-dispatch counter rows are large: keep the summaries only
+rm -rf "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_mfma "$OUT"/trace_default/*kernel_trace.csv "$OUT"/trace_1stream/*kernel_trace.csv
+du -sh "$OUT" | tail -1
+cat "$OUT/pmc_wino43.txt" | tail -30
+head -12 "$OUT/kernel_stats_trace_1stream.txt"
