@@ -175,6 +175,17 @@ int rpg_attention_rows_f32(const float* gtp, int r, int c, float* y, void* strea
 int rpg_scatter_mean_f32(const float* msg, const int32_t* rowptr, const int32_t* perm, int n, int e, int d,
                          float* out, void* stream);
 
+/* AttentionBlock core + mean aggregation fused (att.py:20-31, my_gnn_layer.py:279,301,304-307).  att = W y + b + msg is
+ * linear in (y, msg), so mean_e(att) = W mean_e(y) + (b + mean_e(msg)): this entry point produces the two means per
+ * target node through the CSR of rpg_graph_prepare, in ascending edge order,
+ *   ybar[v][i] = mean_{e -> v} y_e[i]   (y_e = the attention row of gtp[e], as rpg_attention_rows_f32)       [n][c]
+ *   mbar[v][:] = mean_{e -> v} msg[e][:] (+ bias[:] if the node has an incoming edge; bias may be NULL)       [n][d]
+ * (mbar without bias is bit-exact rpg_scatter_mean_f32 of msg; nodes without incoming edges give zeros) and the composite
+ * forward then runs att.W on n rows: agg = ybar W^T + mbar.  gtp [e][3c], msg [e][d]; c % 4 == 0, d % 4 == 0,
+ * d <= 1024 * ceil(c / 64).                                                                                   */
+int rpg_attention_aggregate_f32(const float* gtp, const float* msg, const int32_t* rowptr, const int32_t* perm,
+                                const float* bias, int n, int e, int c, int d, float* ybar, float* mbar, void* stream);
+
 /* Two 3-output Linear heads on the same rows, concatenated: out[r][0:3] = x W1^T + b1,
  * out[r][3:6] = x W2^T + b2 (posenet.py:1077-1091).  w6 [6][d] = cat(W1, W2), b6 [6].           */
 int rpg_pose_heads_f32(const float* x, const float* w6, const float* b6, int r, int d, float* out, void* stream);
@@ -224,7 +235,8 @@ int rpg_linear_bf16(const void* a, const void* weight, const float* bias, const 
 #define RPG_TIMER_SCATTER 2       /* scatter-mean                                                  */
 #define RPG_TIMER_ATTENTION 3     /* attention rows                                                */
 #define RPG_TIMER_CONV_WINO 4     /* Winograd F(4,3) 3x3/stride-1 convolutions (work = direct-conv FLOP) */
-#define RPG_TIMER_COUNT 5
+#define RPG_TIMER_ATT_AGG 5       /* fused attention rows + mean aggregation (work = algorithmic bytes)   */
+#define RPG_TIMER_COUNT 6
 /* enable != 0: every launch of the listed kernel classes is bracketed by hipEventRecord. */
 int rpg_timing_enable(int enable);
 /* Synchronises, sums the elapsed time of all bracketed launches since the last read.
@@ -250,6 +262,8 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
                                      the 26-tensor table) | 0: reference formulation (gathered 3-source GEMMs) */
 #define RPG_TUNE_BF16_BK 6        /* K step of the bf16 convolution kernel: 32 (default) | 64 */
 #define RPG_TUNE_BF16_FAST 9      /* 1: interleaved buffer-load bf16 conv kernel where Cin % 64 == 0 (default) | 0: general kernel */
+#define RPG_TUNE_GNN_FUSE_AGG 13  /* 1: attention rows + mean aggregation in one kernel, att.W on node rows (default) | 0: per-edge
+                                     attention rows, att.W on edge rows, separate scatter-mean (the reference's order) */
 #define RPG_TUNE_WAVES8 11        /* 1: 8-wave workgroups (two waves per SIMD) for the 128x128 / 128x64 tiles of the f32 tile engine where
                                      the buffer-load path applies (default) | 0: always 4-wave workgroups */
 #define RPG_TUNE_FUSED_STEM 10    /* 1: one-kernel stem (conv7x7 + BN + ReLU + max-pool) where its operands are given (default) | 0: three kernels */

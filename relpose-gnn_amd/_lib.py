@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RPG_HIP_LIB") or os.path.join(HERE, "lib", "librelpose_gnn_hip.so")
 
 RPG_OK, RPG_ERR_BAD_ARG, RPG_ERR_LAUNCH, RPG_ERR_WORKSPACE = 0, -1, -2, -3
-TIMER_NAMES = ("conv", "linear", "scatter", "attention", "conv_wino")
+TIMER_NAMES = ("conv", "linear", "scatter", "attention", "conv_wino", "att_agg")
 
 # every symbol include/relpose_gnn_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (
@@ -26,6 +26,7 @@ SYMBOLS = (
     "rpg_conv3x3_wino43_bn_act_nhwc_f32", "rpg_conv2d_bn_act_nhwc_bf16", "rpg_resnet_bf16_workspace_bytes",
     "rpg_resnet_forward_bf16", "rpg_gnn_forward_bf16", "rpg_f32_to_bf16", "rpg_linear_bf16",
     "rpg_release_scratch", "rpg_timing_read_ex", "rpg_stem_conv7x7s2_bn_relu_maxpool_f32", "rpg_stem_pair_table",
+    "rpg_attention_aggregate_f32",
 )
 
 
@@ -58,6 +59,7 @@ def _declare(lib: C.CDLL) -> None:
                                           _vp, _vp, _i, _i, _i, _vp]
     lib.rpg_attention_rows_f32.argtypes = [_vp, _i, _i, _vp, _vp]
     lib.rpg_scatter_mean_f32.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]
+    lib.rpg_attention_aggregate_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]
     lib.rpg_pose_heads_f32.argtypes = [_vp, _vp, _vp, _i, _i, _vp, _vp]
     lib.rpg_gnn_workspace_bytes.argtypes = [_i, _i, _i]
     lib.rpg_gnn_workspace_bytes.restype = _sz

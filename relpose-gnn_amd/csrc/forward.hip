@@ -183,7 +183,7 @@ size_t gnn_bytes(int n, int e, int d) {
     add((size_t)(n + 1) * 4);               // rowptr
     add((size_t)n * 4);                     // cursor
     add((size_t)e * 4);                     // perm
-    add((size_t)e * d * 4, 5);              // e0, e1, hidden, msg, att
+    add((size_t)e * d * 4, 6);              // e0, e1, raw edge update, hidden, msg, att (fused aggregation: mean messages)
     add((size_t)e * 3 * c * 4);             // g|theta|phi
     add((size_t)e * c * 4);                 // y
     add((size_t)n * d * 4, 4);              // agg, node hidden, x ping-pong
@@ -226,6 +226,7 @@ int gnn_forward_impl(const float* const* tensors, int n_tensors, const void* con
     int32_t* cursor = cv.take<int32_t>((size_t)n);
     int32_t* perm = cv.take<int32_t>((size_t)e);
     float* ebuf[2] = {cv.take<float>((size_t)e * d), cv.take<float>((size_t)e * d)};
+    float* eraw = cv.take<float>((size_t)e * d);
     float* hid = cv.take<float>((size_t)e * d);
     float* msg = cv.take<float>((size_t)e * d);
     float* att = cv.take<float>((size_t)e * d);
@@ -248,7 +249,8 @@ int gnn_forward_impl(const float* const* tensors, int n_tensors, const void* con
 
     auto linear = [&](int ns, const float* a0, const int64_t* i0, int w0, const float* a1, const int64_t* i1, int w1,
                       const float* a2, const int64_t* i2, int w2, int wt, const float* residual, float* out, int m,
-                      int n_out, int relu) {
+                      int n_out, int relu, float* out_relu = nullptr, bool with_bias = true) {
+        const float* bias = with_bias ? tensors[wt + 1] : nullptr;
         rpg::GatherSrc g{};
         g.n = ns;
         g.a[0] = a0; g.idx[0] = i0; g.ld[0] = w0; g.width[0] = w0;
@@ -271,10 +273,11 @@ int gnn_forward_impl(const float* const* tensors, int n_tensors, const void* con
             int r2;
             if ((r2 = rpg::launch_f32_to_bf16(a0, w0, abf, k, 0, m, w0, s)) != RPG_OK) return r2;
             if (ns > 1 && (r2 = rpg::launch_f32_to_bf16(a1, w1, abf, k, w0, m, w1, s)) != RPG_OK) return r2;
-            return rpg::launch_linear_bf16(abf, wb[bw], tensors[wt + 1], residual, nullptr, nullptr, nullptr, n_out, out, m, k,
+            if (out_relu) return RPG_ERR_BAD_ARG;          // the bf16 Linears have no dual-store epilogue
+            return rpg::launch_linear_bf16(abf, wb[bw], bias, residual, nullptr, nullptr, nullptr, n_out, out, m, k,
                                            n_out, relu, s);
         }
-        return rpg::launch_linear(g, tensors[wt], tensors[wt + 1], residual, out, m, n_out, relu, s);
+        return rpg::launch_linear(g, tensors[wt], bias, residual, out, m, n_out, relu, s, nullptr, out_relu);
     };
 
     // A Linear fed by cat[x[a], x[b], e] splits as W_a x[a] + W_b x[b] + W_e e: the node terms are computed once per
@@ -314,8 +317,11 @@ int gnn_forward_impl(const float* const* tensors, int n_tensors, const void* con
         return rc;
     }
 
+    const bool fuse_agg = rpg::gnn_fuse_agg_enabled();
+    const bool dual = !wb;                 // fp32: the edge update is stored twice, raw (for the message) and rectified
     for (int r = 0; r < gnn_recursion; ++r) {                                           // posenet.py:1061-1069
-        float* enew = (ecur == ebuf[0]) ? ebuf[1] : ebuf[0];
+        float* enext = (ecur == ebuf[0]) ? ebuf[1] : ebuf[0];    // relu(edge update): the next recursion's / the heads' input
+        float* enew = dual ? eraw : enext;                        // the raw edge update (consumed by the message MLP)
         float* xnew = xbuf[r & 1];
         // edge update: edge_mlp(cat[x[src], x[dst], e])                                 my_gnn_layer.py:296-297
         if (split) {
@@ -324,7 +330,10 @@ int gnn_forward_impl(const float* const* tensors, int n_tensors, const void* con
         } else if ((rc = linear(3, x, src, d, x, dst, d, ecur, nullptr, d, T_EDGE0_W, nullptr, hid, e, d, 1)) != RPG_OK) {
             return rc;
         }
-        if ((rc = linear(1, hid, nullptr, d, nullptr, nullptr, 0, nullptr, nullptr, 0, T_EDGE2_W, nullptr, enew, e, d, 0)) != RPG_OK) return rc;
+        // edge_feat = relu(edge_feat) of posenet.py:1065 is the second output of this Linear's epilogue (fp32 path)
+        if ((rc = linear(1, hid, nullptr, d, nullptr, nullptr, 0, nullptr, nullptr, 0, T_EDGE2_W, nullptr, enew, e, d, 0,
+                         dual ? enext : nullptr)) != RPG_OK)
+            return rc;
         // message: mlp(cat[x[src], e_new]) then AttentionBlock                          my_gnn_layer.py:304-307
         if (split) {
             if ((rc = edge_gemm(enew, T_MSG0E_W, T_MSG0_B, node3 + 2 * d, src, nullptr, nullptr, hid)) != RPG_OK) return rc;
@@ -333,16 +342,28 @@ int gnn_forward_impl(const float* const* tensors, int n_tensors, const void* con
         }
         if ((rc = linear(1, hid, nullptr, d, nullptr, nullptr, 0, nullptr, nullptr, 0, T_MSG2_W, nullptr, msg, e, d, 0)) != RPG_OK) return rc;
         if ((rc = linear(1, msg, nullptr, d, nullptr, nullptr, 0, nullptr, nullptr, 0, T_GTP_W, nullptr, gtp, e, 3 * c, 0)) != RPG_OK) return rc;
-        if ((rc = rpg_attention_rows_f32(gtp, e, c, yat, stream)) != RPG_OK) return rc;
-        if ((rc = linear(1, yat, nullptr, c, nullptr, nullptr, 0, nullptr, nullptr, 0, T_ATTW_W, msg, att, e, d, 0)) != RPG_OK) return rc;
-        // aggregate (mean over incoming edges) and node update                          my_gnn_layer.py:301,309-311
-        if ((rc = rpg_scatter_mean_f32(att, rowptr, perm, n, e, d, agg, stream)) != RPG_OK) return rc;
+        if (fuse_agg) {
+            // aggregate FIRST (att = W y + b + msg is linear in (y, msg): mean(att) = W mean(y) + b + mean(msg)), in the
+            // attention kernel itself, then att.W on the n node rows                    my_gnn_layer.py:301,304-307; att.py:32-33
+            if ((rc = rpg_attention_aggregate_f32(gtp, msg, rowptr, perm, tensors[T_ATTW_B], n, e, c, d, yat, att, stream)) != RPG_OK)
+                return rc;
+            if ((rc = linear(1, yat, nullptr, c, nullptr, nullptr, 0, nullptr, nullptr, 0, T_ATTW_W, att, agg, n, d, 0, nullptr,
+                             false)) != RPG_OK)
+                return rc;
+        } else {
+            if ((rc = rpg_attention_rows_f32(gtp, e, c, yat, stream)) != RPG_OK) return rc;
+            if ((rc = linear(1, yat, nullptr, c, nullptr, nullptr, 0, nullptr, nullptr, 0, T_ATTW_W, msg, att, e, d, 0)) != RPG_OK) return rc;
+            // aggregate (mean over incoming edges)                                       my_gnn_layer.py:301
+            if ((rc = rpg_scatter_mean_f32(att, rowptr, perm, n, e, d, agg, stream)) != RPG_OK) return rc;
+        }
+        // node update                                                                   my_gnn_layer.py:309-311
         if ((rc = linear(2, x, nullptr, d, agg, nullptr, d, nullptr, nullptr, 0, T_UPD0_W, nullptr, nhid, n, d, 1)) != RPG_OK) return rc;
         if ((rc = linear(1, nhid, nullptr, d, nullptr, nullptr, 0, nullptr, nullptr, 0, T_UPD2_W, nullptr, xnew, n, d, 1)) != RPG_OK) return rc;
-        // x = relu(x) is fused above; edge_feat = relu(edge_feat) now that the message has consumed the raw one
-        if ((rc = rpg::launch_relu_inplace(enew, (long)e * d, s)) != RPG_OK) return rc;
+        // x = relu(x) is fused above; edge_feat = relu(edge_feat): dual-stored above, or in place now that the message has
+        // consumed the raw one (bf16 Linears)
+        if (!dual && (rc = rpg::launch_relu_inplace(enext, (long)e * d, s)) != RPG_OK) return rc;
         x = xnew;
-        ecur = enew;
+        ecur = enext;
     }
     if (node_out && hipMemcpyAsync(node_out, x, (size_t)n * d * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) {
         rpg::set_last_error("gnn_forward node_out", hipGetLastError());

@@ -47,6 +47,7 @@ struct Epilogue {
     const float* residual2 = nullptr;     // second gathered residual (pitch ldr), or null
     const int64_t* res2_idx = nullptr;
     int ldr = 0;                          // pitch of gathered residual rows
+    float* out_relu = nullptr;            // optional second output [M][ldc] = max(out, 0) (the same values, rectified)
 };
 
 // byte-free helpers: element offset of row m's residual(s)
@@ -103,6 +104,7 @@ int g_bk = 0;                        // 0 = automatic: 32 for the 128x128 tile (
 int g_epi_lds = 1;
 int g_streamk = 1;
 int g_gnn_split = 1;
+int g_gnn_fuse_agg = 1;
 constexpr int SK_MIN_ITS = 8;        // at least this many k-steps per stream-K workgroup
 constexpr int SK_MIN_NK = 32;        // tiles with fewer k-steps are not worth splitting (fix-up traffic dominates)
 
@@ -253,6 +255,7 @@ int launch_tiles(const Args& args, const float* Wt, int ldw, int M, int N, int K
 namespace rpg {
 
 bool gnn_split_enabled() { return g_gnn_split != 0; }
+bool gnn_fuse_agg_enabled() { return g_gnn_fuse_agg != 0; }
 float* stream_scratch(hipStream_t s, size_t bytes) { return get_scratch(s, bytes); }
 ScratchScope::ScratchScope(void* p, size_t bytes) {
     t_scratch.p = static_cast<float*>(p);
@@ -289,7 +292,7 @@ int launch_conv(const float* x, const float* w, const float* scale, const float*
 }
 
 int launch_linear(const GatherSrc& src, const float* weight, const float* bias, const float* residual, float* out,
-                  int m, int n_out, int relu, hipStream_t s, const GatherRes* gres) {
+                  int m, int n_out, int relu, hipStream_t s, const GatherRes* gres, float* out_relu) {
     if (src.n < 1 || src.n > 3 || !weight || !out || m <= 0 || n_out <= 0 || !aligned16(weight)) return RPG_ERR_BAD_ARG;
     GatherArgs a{};
     int K = 0;
@@ -308,6 +311,8 @@ int launch_linear(const GatherSrc& src, const float* weight, const float* bias, 
     a.w01 = src.n >= 2 ? src.width[0] + src.width[1] : K;
     a.K = K;
     Epilogue ep{nullptr, bias, residual, out, n_out, relu};
+    ep.out_relu = out_relu;
+    if (out_relu && !aligned16(out_relu)) return RPG_ERR_BAD_ARG;
     if (gres) {
         if (!gres->res1 || !gres->idx1 || gres->ld < n_out || (gres->res2 && !gres->idx2)) return RPG_ERR_BAD_ARG;
         ep.residual = gres->res1; ep.res_idx = gres->idx1;
@@ -373,6 +378,7 @@ extern "C" int rpg_set_tuning(int key, int value) {
         case RPG_TUNE_STREAMK: g_streamk = value != 0; return RPG_OK;
         case RPG_TUNE_BF16_BK: if (value != 32 && value != 64) return RPG_ERR_BAD_ARG; rpg::bf16_set_bk(value); return RPG_OK;
         case RPG_TUNE_GNN_SPLIT: g_gnn_split = value != 0; return RPG_OK;
+        case RPG_TUNE_GNN_FUSE_AGG: g_gnn_fuse_agg = value != 0; return RPG_OK;
         case RPG_TUNE_FAST_LOADER: g_fast = value != 0; return RPG_OK;
         case RPG_TUNE_WAVES8: g_waves8 = value != 0; return RPG_OK;
         case RPG_TUNE_WINO_SPLIT: rpg::wino_split_set(value != 0); return RPG_OK;

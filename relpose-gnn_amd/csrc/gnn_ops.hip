@@ -182,6 +182,96 @@ __global__ __launch_bounds__(NT) void attention_rows_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// AttentionBlock core + mean aggregation in one kernel (the message path of my_gnn_layer.py:304-307 followed by PyG's
+// aggr='mean', :279,301).  The reference computes, per edge, att = W y + b + msg with y = the attention rows of above, and
+// then averages att over the edges into a node.  W y + b + msg is linear in (y, msg), so the mean commutes with it:
+//   mean_e(att) = W mean_e(y) + (b + mean_e(msg))            (summation order changes only)
+// and the E-row Linear att.W becomes an N-row one.  This kernel produces the two means for a node directly:
+//   ybar[v][i] = (1/cnt) sum_{e -> v} y_e[i],   mbar[v][:] = (1/cnt) sum_{e -> v} msg[e][:] (+ bias if cnt > 0)
+// in ascending edge order (the order of torch_scatter's CPU kernel; mbar without bias is BIT-EXACT scatter-mean of msg),
+// so neither the per-edge y [E][C], nor att [E][D], nor a separate scatter launch exist any more.
+// Workgroup (node v, quarter s): 256 threads = 64 channels (i = 64 s + t % 64) x 4 j-quarters (wave = t / 64): a thread
+// accumulates exp(phi_i theta_j - m_i) (g_j) over its 64 j, the quarters are combined through LDS; threads 0..D/16-1
+// also carry one float4 column of mbar.  An isolated node (cnt = 0) gives zeros, like scatter-mean.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void attention_aggregate_kernel(const float* __restrict__ gtp, const float4* __restrict__ msg,
+                                                                 const int* __restrict__ rowptr, const int* __restrict__ perm,
+                                                                 const float4* __restrict__ bias, int C, int d4,
+                                                                 float* __restrict__ ybar, float4* __restrict__ mbar) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // theta[C], g[C], red[8], part[2][4][64]
+    float* s_th = sm;
+    float* s_g = sm + C;
+    float* s_red = sm + 2 * C;
+    float* s_part = sm + 2 * C + 8;
+    const int v = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, wave = tid >> 6;
+    const int i = 64 * s + (tid & 63);                    // this thread's output channel (valid if < C)
+    const int beg = rowptr[v], end = rowptr[v + 1];
+    const int dq = (d4 + gridDim.y - 1) / gridDim.y;      // float4 columns of mbar per quarter
+    const int mc = s * dq + tid;                          // this thread's mbar column (valid if tid < dq && mc < d4)
+    const bool m_ok = tid < dq && mc < d4;
+    float yacc = 0.f;
+    float4 macc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = beg; p < end; ++p) {
+        const int e = perm[p];
+        const float* row = gtp + (size_t)e * 3 * C;
+        __syncthreads();                                  // the previous row's LDS is consumed
+        float tmax = -INFINITY, tmin = INFINITY;
+        for (int j = tid; j < C; j += NT) {
+            const float th = row[C + j];
+            s_th[j] = th;
+            s_g[j] = row[j];
+            tmax = fmaxf(tmax, th);
+            tmin = fminf(tmin, th);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            tmax = fmaxf(tmax, __shfl_xor(tmax, off));
+            tmin = fminf(tmin, __shfl_xor(tmin, off));
+        }
+        if ((tid & 63) == 0) { s_red[wave] = tmax; s_red[4 + wave] = tmin; }
+        if (m_ok) {
+            const float4 mv = msg[(size_t)e * d4 + mc];
+            macc.x += mv.x; macc.y += mv.y; macc.z += mv.z; macc.w += mv.w;
+        }
+        __syncthreads();
+        tmax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        tmin = fminf(fminf(s_red[4], s_red[5]), fminf(s_red[6], s_red[7]));
+        float den = 0.f, num = 0.f;
+        if (i < C) {
+            const float phi = row[2 * C + i];
+            const float m = __fmul_rn(phi, (phi >= 0.f ? tmax : tmin));
+            const int jq = (C + 3) / 4, j0 = wave * jq, j1 = min(C, j0 + jq);
+            for (int j = j0; j < j1; ++j) {
+                // product and subtraction rounded separately (no FMA contraction), as the reference's matmul-then-softmax
+                const float pe = __expf(__fsub_rn(__fmul_rn(phi, s_th[j]), m));
+                den += pe;
+                num += pe * s_g[j];
+            }
+        }
+        s_part[wave * 64 + (tid & 63)] = den;
+        s_part[256 + wave * 64 + (tid & 63)] = num;
+        __syncthreads();
+        if (wave == 0 && i < C) {
+            const int l = tid & 63;
+            const float dsum = ((s_part[l] + s_part[64 + l]) + s_part[128 + l]) + s_part[192 + l];
+            const float nsum = ((s_part[256 + l] + s_part[320 + l]) + s_part[384 + l]) + s_part[448 + l];
+            yacc += nsum / dsum;
+        }
+    }
+    const int cnt = end - beg;
+    const float dv = (float)(cnt > 0 ? cnt : 1);
+    if (wave == 0 && i < C) ybar[(size_t)v * C + i] = yacc / dv;
+    if (m_ok) {
+        float4 o = make_float4(macc.x / dv, macc.y / dv, macc.z / dv, macc.w / dv);
+        if (bias && cnt > 0) {
+            const float4 b = bias[mc];
+            o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+        }
+        mbar[(size_t)v * d4 + mc] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // scatter-mean: one workgroup per (target node, 1024-column slab); every lane streams its float4 column of
 // the node's incoming messages in ascending edge order (4 independent loads in flight) and divides by the
 // in-degree.  Algorithmic bytes: E*D*4 (messages) + N*D*4 (output) + indices.
@@ -400,6 +490,26 @@ extern "C" int rpg_attention_rows_f32(const float* gtp, int r, int c, float* y, 
     hipLaunchKernelGGL(attention_rows_kernel, dim3(r), dim3(NT), (2 * c + 8) * sizeof(float), s, gtp, c, y);
     rpg::timing_end(slot, (double)r * c * (double)c * 4.0, s);
     RPG_CHECK_LAUNCH("attention_rows");
+    return RPG_OK;
+}
+
+extern "C" int rpg_attention_aggregate_f32(const float* gtp, const float* msg, const int32_t* rowptr, const int32_t* perm,
+                                           const float* bias, int n, int e, int c, int d, float* ybar, float* mbar,
+                                           void* stream) {
+    if (!gtp || !msg || !rowptr || !perm || !ybar || !mbar || n <= 0 || e <= 0 || c <= 0 || d <= 0 || (c & 3) || (d & 3) ||
+        c > 4096 || !rpg::aligned16(gtp) || !rpg::aligned16(msg) || !rpg::aligned16(mbar) || (bias && !rpg::aligned16(bias)))
+        return RPG_ERR_BAD_ARG;
+    hipStream_t s = rpg::as_stream(stream);
+    const int quarters = (c + 63) / 64;                       // 64 output channels per workgroup
+    if ((d / 4 + quarters - 1) / quarters > NT) return RPG_ERR_BAD_ARG;      // one mbar column per thread
+    const int slot = rpg::timing_begin(RPG_TIMER_ATT_AGG, s);
+    hipLaunchKernelGGL(attention_aggregate_kernel, dim3(n, quarters), dim3(NT), (2 * c + 8 + 512) * sizeof(float), s, gtp,
+                       reinterpret_cast<const float4*>(msg), rowptr, perm, reinterpret_cast<const float4*>(bias), c, d / 4, ybar,
+                       reinterpret_cast<float4*>(mbar));
+    // algorithmic bytes: the scatter-mean of SURVEY 8(a) A9 (messages E*D*4 + targets E*8 + output N*D*4) plus the attention
+    // operands it now reads itself (E*3C*4) and the N*C*4 it writes
+    rpg::timing_end(slot, (double)e * d * 4.0 + (double)e * 8.0 + (double)n * d * 4.0 + (double)e * 3.0 * c * 4.0 + (double)n * c * 4.0, s);
+    RPG_CHECK_LAUNCH("attention_aggregate");
     return RPG_OK;
 }
 

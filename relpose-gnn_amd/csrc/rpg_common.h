@@ -88,11 +88,13 @@ struct GatherRes {
     const int64_t* idx2;
     int ld;
 };
+// out_relu: optional second output of the same shape, = max(out, 0)
 int launch_linear(const GatherSrc& src, const float* weight, const float* bias, const float* residual, float* out,
-                  int m, int n_out, int relu, hipStream_t s, const GatherRes* gres = nullptr);
+                  int m, int n_out, int relu, hipStream_t s, const GatherRes* gres = nullptr, float* out_relu = nullptr);
 int launch_gather_add2_relu(const float* pq, const int64_t* lo, const int64_t* hi, const float* bias, float* out, int e,
                             int d, hipStream_t s);
 bool gnn_split_enabled();
+bool gnn_fuse_agg_enabled();
 void bf16_set_bk(int bk);
 
 }  // namespace rpg

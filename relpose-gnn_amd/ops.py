@@ -255,6 +255,22 @@ def scatter_mean(msg: torch.Tensor, rowptr: torch.Tensor, perm: torch.Tensor, n:
     return out
 
 
+def attention_aggregate(gtp: torch.Tensor, msg: torch.Tensor, rowptr: torch.Tensor, perm: torch.Tensor, n: int,
+                        bias: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(ybar [n, c], mbar [n, d]): per-node means of the attention rows of gtp [e, 3c] and of msg [e, d] (+ bias on nodes
+    with incoming edges), ascending edge order; see rpg_attention_aggregate_f32."""
+    gtp, msg = _req(gtp, "gtp"), _req(msg, "msg")
+    rowptr, perm = _req(rowptr, "rowptr", torch.int32), _req(perm, "perm", torch.int32)
+    bias = None if bias is None else _req(bias, "bias")
+    e, c3 = gtp.shape
+    c, d = c3 // 3, msg.shape[1]
+    ybar = torch.empty((n, c), dtype=torch.float32, device=gtp.device)
+    mbar = torch.empty((n, d), dtype=torch.float32, device=gtp.device)
+    L.check(L.lib().rpg_attention_aggregate_f32(_p(gtp), _p(msg), _p(rowptr), _p(perm), _p(bias), n, e, c, d, _p(ybar), _p(mbar),
+                                                _stream()), "attention_aggregate")
+    return ybar, mbar
+
+
 def pose_heads(x: torch.Tensor, w6: torch.Tensor, b6: torch.Tensor) -> torch.Tensor:
     x, w6, b6 = _req(x, "x"), _req(w6, "w6"), _req(b6, "b6")
     r, d = x.shape
@@ -280,7 +296,7 @@ def release_scratch() -> None:
     L.check(L.lib().rpg_release_scratch(), "release_scratch")
 
 
-TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST, TUNE_FUSED_STEM, TUNE_WAVES8, TUNE_WINO_SHORT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
+TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST, TUNE_FUSED_STEM, TUNE_WAVES8, TUNE_WINO_SHORT, TUNE_GNN_FUSE_AGG = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
 
 
 def set_tuning(key: int, value: int) -> None:

@@ -363,6 +363,28 @@ def test_gnn_node_split_equals_reference_formulation(dev, golden_dir):
     assert ea < TOL and er < TOL
 
 
+def test_gnn_fused_aggregation_equals_reference_order(dev):
+    """Default GNN forward (attention rows + mean aggregation fused, att.W on node rows, dual-stored ReLU of the edge update)
+    vs the reference's order of the same operations (RPG_TUNE_GNN_FUSE_AGG = 0: per-edge attention rows, att.W on edge rows,
+    separate scatter-mean): same poses up to fp32 summation order, at the R3 width, both recursions, 3 ragged graphs."""
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd import ops
+    from relpose_gnn_amd.graph import Batch, Data, fc_edge_index
+    m, _ = _build(2048, 64, (64, 128, 256, 512), (3, 4, 6, 3), dev)
+    graphs = [Data(x=S.synth_images(k, 64, 64, seed=300 + i), edge_index=fc_edge_index(k)) for i, k in enumerate((8, 5, 8))]
+    b = Batch.from_data_list(graphs).to(dev)
+    m.hip_streams = 1
+    a1, r1, _ = m(b)
+    ops.set_tuning(ops.TUNE_GNN_FUSE_AGG, 0)
+    try:
+        a0, r0, _ = m(b)
+    finally:
+        ops.set_tuning(ops.TUNE_GNN_FUSE_AGG, 1)
+    ea, er = rel_err(a1, a0), rel_err(r1, r0)
+    _report("gnn_fused_aggregation_vs_reference_order_R3_64px", ea, er)
+    assert ea < TOL and er < TOL, (ea, er)
+
+
 def test_graph_replay_equals_eager(dev):
     """The forward captured into a HIP graph (both worker streams joined by events) replays to the same poses, also
     after the static input has been overwritten with a new batch."""

@@ -222,6 +222,44 @@ def test_scatter_mean_isolated_nodes(dev):
     assert float(out[[1, 2, 4, 5]].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("sizes,c,d", [((8, 8, 8, 8), 256, 2048), ((8, 4, 1, 6), 8, 64), ((5, 3), 64, 200)])
+def test_attention_aggregate(dev, sizes, c, d):
+    """rpg_attention_aggregate_f32 (attention rows + mean aggregation in one kernel; att.py:20-31 + PyG aggr='mean',
+    my_gnn_layer.py:279,301): mbar without bias is BIT-EXACT scatter-mean of the messages (oracle, ascending edge order,
+    isolated nodes -> 0), ybar = scatter-mean of the attention rows (1e-5), the bias lands only on nodes with incoming
+    edges, and W ybar + mbar equals the reference's mean of (W y + b + msg)."""
+    from relpose_gnn_amd import ops
+    from oracle.posenet_ref import fc_edge_index, scatter_mean
+    eis, off = [], 0
+    for n_nodes in sizes:
+        if n_nodes > 1:
+            eis.append(fc_edge_index(n_nodes) + off)
+        off += n_nodes
+    n = off + 2                                             # two trailing nodes without any edge
+    ei = torch.cat(eis, 1)
+    e = ei.shape[1]
+    gtp = _rand(e, 3 * c, seed=9, scale=1.5)
+    msg = _rand(e, d, seed=10)
+    bias = _rand(d, seed=11)
+    g_, th, ph = gtp[:, :c], gtp[:, c:2 * c], gtp[:, 2 * c:]
+    y = torch.bmm(torch.softmax(ph.unsqueeze(2) * th.unsqueeze(1), dim=-1), g_.unsqueeze(2)).squeeze(2)
+    gp = ops.graph_prepare(ei.to(dev), n)
+    ybar, mbar = ops.attention_aggregate(gtp.to(dev), msg.to(dev), gp["rowptr"], gp["perm"], n)
+    assert torch.equal(mbar.cpu(), scatter_mean(msg, ei[1], n))                       # bit-exact (A9)
+    assert rel_err(ybar.cpu(), scatter_mean(y, ei[1], n)) < TOL
+    assert float(ybar[-2:].abs().max()) == 0.0 and float(mbar[-2:].abs().max()) == 0.0
+    _, mb = ops.attention_aggregate(gtp.to(dev), msg.to(dev), gp["rowptr"], gp["perm"], n, bias.to(dev))
+    has_in = torch.zeros(n, dtype=torch.bool)
+    has_in[ei[1]] = True
+    assert rel_err(mb.cpu(), scatter_mean(msg, ei[1], n) + bias * has_in.unsqueeze(1)) < 1e-6
+    assert float(mb[-2:].abs().max()) == 0.0
+    # the restructured aggregate == the reference's order (per-edge att, then mean)
+    w = _rand(d, c, seed=12, scale=c ** -0.5)
+    ref = scatter_mean(F.linear(y, w, bias) + msg, ei[1], n)
+    got = ops.linear_gather([(ybar, None)], w.to(dev), None, n, residual=mb)
+    assert rel_err(got.cpu(), ref) < TOL
+
+
 def test_pose_heads(dev):
     from relpose_gnn_amd import ops
     x, w6, b6 = _rand(61, 2048, seed=2), _rand(6, 2048, seed=3, scale=0.02), _rand(6, seed=4)

@@ -16,4 +16,5 @@ d = json.loads(line[-1])
 r = d.get("roofline", {})
 print(f"value {d['value']} graphs/s  {d['ms_per_step']} ms/step | wino avg {r.get('avg_launch_ms')} ms frac {r.get('frac')} | 1-stream: {r.get('measured_on', '')[60:130]}")
 for k, v in d.get("other_kernels", {}).items():
-    print(f"   {k:18s} {v.get('achieved')} {v.get('unit')}  frac {v.get('frac')}  avg {v.get('avg_launch_ms')} ms x {v.get('launches')}")
+    if isinstance(v, dict):
+        print(f"   {k:18s} {v.get('achieved')} {v.get('unit')}  frac {v.get('frac')}  avg {v.get('avg_launch_ms')} ms x {v.get('launches')}")
