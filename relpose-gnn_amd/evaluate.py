@@ -121,7 +121,7 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 32
             ev.synchronize()
         check = getattr(model, "check_edge_index", None)
         if check is not None:
-            check()            # the bad-edge counters were copied before `ev`: no further wait (IndexError like the reference)
+            check(wait=False)  # this batch's bad-edge counters were copied before `ev`: look, do not wait for the NEXT batch
         rel = host.numpy()
         if host_ei is not None:
             ei = host_ei.numpy()
@@ -150,6 +150,8 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 32
         pending = item
     if pending is not None:
         finish(pending)
+    if getattr(model, "check_edge_index", None) is not None:
+        model.check_edge_index()                       # everything has been issued: wait for the last report
     pred = np.stack(preds) if preds else np.zeros((0, 7))
     targ = np.stack(targs) if targs else np.zeros((0, 7))
     if world > 1:

@@ -240,10 +240,21 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         self._status_event.record()
         self._status_pending = True
 
-    def check_edge_index(self) -> None:
-        """Block until every forward issued so far has reported, and raise IndexError if any had an edge with a node id
-        out of range (the error the reference's indexing raises at the call itself)."""
-        self._poll_status(block=True)
+    def check_edge_index(self, wait: bool = True) -> None:
+        """Raise IndexError if a forward issued so far had an edge with a node id out of range (the error the reference's
+        indexing raises at the call itself).  ``wait=True`` blocks until EVERY forward issued so far has reported.
+        ``wait=False`` only looks at what has already arrived in the pinned mirror: for a caller that has just synchronised
+        on a later event of the same stream (``evaluate_stream`` after its device-to-host copy of batch i, with batch i+1
+        already enqueued) that covers batch i without waiting for batch i+1; the counters accumulate on the device, so a
+        report that is not in yet is seen by the next look."""
+        if wait:
+            self._poll_status(block=True)
+            return
+        if self._status_host is not None:
+            bad = int(self._status_host.sum())
+            if bad:
+                self._status_event.synchronize()
+                self._raise_bad_edges(bad)
 
     def _gnn_call(self, lib, feat, esrc_ptr, edst_ptr, node_off, n, e, abs_pose, rel_pose, node_f, edge_f, status, slot):
         d = feat.shape[1]

@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=32)
     ap.add_argument("--encoder-dtype", choices=("f32", "bf16"), default="f32")
     ap.add_argument("--gnn-dtype", choices=("f32", "bf16"), default="f32")
+    ap.add_argument("--knn", type=int, default=-1, help="the reference's --knn (test.py:308 defaults to 4): the model rebuilds "
+                    "the graph from the encoder features (posenet.py:1047-1048); -1 = the stored fully-connected edges")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="rpg_set_tuning(KEY, VALUE) before the run (A/B)")
     args = ap.parse_args()
     h, w = (int(v) for v in args.shape.split("x"))
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -47,11 +50,15 @@ def main():
 
     D = 2048
     model = PoseNetX_R2(resnet34(), droprate=0.0, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D,
-                        input_img_height=h, use_gnn=True, knn=-1, use_AP=True, gnn_recursion=2)
+                        input_img_height=h, use_gnn=True, knn=args.knn, use_AP=True, gnn_recursion=2)
     model.load_state_dict(S.synth_state_dict(S.posenet_r2_param_shapes(D, D, D), seed=1))
     model = model.to(dev).eval()
     model.encoder_dtype = args.encoder_dtype
     model.gnn_dtype = args.gnn_dtype
+    from relpose_gnn_amd import ops
+    for kv in args.tune:
+        k, v = kv.split("=")
+        ops.set_tuning(int(k), int(v))
 
     lo, hi = shard_range(args.graphs, rank, world)
     mb = args.micro_batch
@@ -69,9 +76,18 @@ def main():
         y_host = y.cpu().numpy()
 
         def finish(item):
-            g, host, ev = item
+            g, host, host_ei, ev = item
             ev.synchronize()
+            model.check_edge_index(wait=False)           # this micro-batch's device-side index check landed with `ev`
             rel_c = host.numpy()
+            if host_ei is not None:                      # model-built (kNN) edges: cut per graph by the target node's graph
+                ei = host_ei.numpy()
+                gid = ei[1] // 8
+                for k in range(g):
+                    cols = np.flatnonzero(gid == k)
+                    p, _ = E.query_pose(rel_c[cols], y_host[8 * k: 8 * (k + 1)], ei[:, cols] - 8 * k, pm, ps)
+                    preds.append(p)
+                return
             for k in range(g):
                 p, _ = E.query_pose(rel_c[56 * k: 56 * (k + 1)], y_host[8 * k: 8 * (k + 1)], ei_local, pm, ps)
                 preds.append(p)
@@ -81,17 +97,22 @@ def main():
             batch = fc_batch(x[: 8 * g], 8, y[: 8 * g])
             if ei_local is None:
                 ei_local = batch.edge_index[:, :56].cpu().numpy()
-            _, rel, _ = model(batch)
+            _, rel, ei_out = model(batch)
             host = torch.empty(rel.shape, dtype=rel.dtype, pin_memory=True)
             host.copy_(rel, non_blocking=True)                                  # D2H as test.py:214 does, asynchronously
+            host_ei = None
+            if ei_out is not batch.edge_index:
+                host_ei = torch.empty(ei_out.shape, dtype=ei_out.dtype, pin_memory=True)
+                host_ei.copy_(ei_out, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             if pending is not None:
                 finish(pending)
-            pending = (g, host, ev)
+            pending = (g, host, host_ei, ev)
             done += g
         if pending is not None:
             finish(pending)
+        model.check_edge_index()
         return np.stack(preds) if preds else np.zeros((0, 7))
 
     run(min(mb, hi - lo))                                                      # warm-up (packing, workspaces)
@@ -112,7 +133,7 @@ def main():
     if rank == 0:
         assert len(poses) == args.graphs
         print(json.dumps({"workload": f"eval-shape stream: {args.graphs} 8-node FC graphs, {h}x{w}, encoder {args.encoder_dtype}, GNN Linears {args.gnn_dtype}, "
-                                      f"micro-batch {mb}, pipelined D2H + test.py post-processing per graph included",
+                                      f"knn {args.knn}, micro-batch {mb}, pipelined D2H + test.py post-processing per graph included",
                           "n_gpus": world, "graphs": args.graphs, "seconds": round(dt, 3),
                           "graphs_per_s": round(args.graphs / dt, 1)}), flush=True)
     if world > 1:
