@@ -295,8 +295,8 @@ def main():
                         "counted by the launcher; equals SQ_INSTS_VALU_MFMA_F32 x 4096 of the PMC profile) / their summed "
                         "HIP-event durations",
                 "kernel": "wino43_conv8_kernel (3x3/stride-1 conv + BN (+residual) + ReLU as 1-D Winograd F(4,3) on "
-                          "v_mfma_f32_32x32x2_f32; 29 of the 36 ResNet34 convolutions); a launch = the <false> main kernel "
-                          "plus, on layers with a tail, its split-K <true> kernel and wino43_fixup_kernel",
+                          "v_mfma_f32_32x32x2_f32; 29 of the 36 ResNet34 convolutions); a launch = the kernel (whole tiles "
+                          "and, on layers with a tail, its split-K workgroups in the same grid) plus wino43_fixup_kernel",
                 "launches": c["launches"], "avg_launch_ms": round(avg_ms, 4),
                 "executed_gflop_per_launch": round(c["executed"] / c["launches"] / 1e9, 3),
                 "algorithmic": {"gflop_per_launch": round(c["work"] / c["launches"] / 1e9, 3), "tflops": round(alg, 2),

@@ -15,7 +15,7 @@
 // Two kernels share the addressing, the LDS layout (64-byte rows of four 16-byte chunks, XOR-swizzled by row) and
 // the epilogue (output transform, LDS transpose, BatchNorm / residual / ReLU through raw buffer accesses):
 //   * wino43_conv8_kernel (the one that matters): 8 waves on 128 tiles x 64 channels, two LDS images of a 16-wide K
-//     step, one barrier per step, every load / LDS access placed singly behind an MFMA; <true> is its split-K
+//     step, one barrier per step, every load / LDS access placed singly behind an MFMA; its first blocks are the split-K
 //     variant for the tiles beyond the last full round of CUs, finished by wino43_fixup_kernel;
 //   * wino43_conv_kernel: 4 waves on 64 tiles x 64 channels, one LDS image, two workgroups per CU: small grids.
 // The design rules come from tools/probes/mfma_shadow_probe.hip: VALU time does not hide behind f32 MFMAs on gfx950.
@@ -411,10 +411,13 @@ RPG_F4_OP(add4, pk_add)
 RPG_F4_OP(sub4, pk_sub)
 #undef RPG_F4_OP
 
-// SPLIT: the tiles [tile_base, ..) that do not fill a whole round of CUs are cut along K into `parts` workgroups each,
+// Split-K tail: the tiles [tile_base, ..) that do not fill a whole round of CUs are cut along K into `parts` workgroups each,
 // which store their raw partial output tile (after the output transform: it is linear) as [512 px][64 ch] in slab
 // (tile - tile_base) * parts + part of `partial`; wino43_fixup_kernel adds the parts in k order and applies the epilogue.
-struct Split { int tile_base, parts; float* partial; };
+// The n_split = (tiles - tile_base) * parts split workgroups are the FIRST blocks of the same launch as the whole tiles
+// (round 2): as a launch of their own (round 1) they ran after the main kernel on a third of the CUs for ~25 us per
+// convolution; now they are over before the first round of whole tiles ends and only the fix-up kernel follows.
+struct Split { int tile_base, parts, n_split; float* partial; };
 
 #ifdef RPG_WINO_TRACE
 // Timeline instrumentation (tools/probes/wino_trace.sh): per workgroup {HW_ID, s_memtime at entry, after the prologue, after
@@ -422,19 +425,18 @@ struct Split { int tile_base, parts; float* partial; };
 __device__ unsigned long long* g_wino_trace = nullptr;
 #define RPG_TRACE(i)                                                                         \
     do {                                                                                     \
-        if (!SPLIT && g_wino_trace && threadIdx.x == 0) g_wino_trace[5 * blockIdx.x + (i)] = __builtin_readcyclecounter(); \
+        if (g_wino_trace && threadIdx.x == 0) g_wino_trace[5 * blockIdx.x + (i)] = __builtin_readcyclecounter(); \
     } while (0)
 #else
 #define RPG_TRACE(i) do {} while (0)
 #endif
 
-template <bool SPLIT>
 __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restrict__ x, const float* __restrict__ U, int H,
                                                           int W, int Cin, int Cout, int Tw, int M, Epi ep, int tiles_n,
                                                           Split sp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef RPG_WINO_TRACE
-    if (!SPLIT && g_wino_trace && threadIdx.x == 0) g_wino_trace[5 * blockIdx.x] = __builtin_amdgcn_s_getreg(0xF804);   // HW_ID
+    if (g_wino_trace && threadIdx.x == 0) g_wino_trace[5 * blockIdx.x] = __builtin_amdgcn_s_getreg(0xF804);   // HW_ID
 #endif
     RPG_TRACE(1);
     const int K = 3 * Cin;
@@ -446,13 +448,14 @@ __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restri
     // read traffic, FETCH_SIZE calibrated with tools/probes/fetch_calib_probe.hip.)
     const int kpr = (Cin + BK - 1) / BK;               // channel blocks = K steps per kernel row
     int tile, kb = 0, nk = 3 * kpr;                    // this workgroup's tile and K-step range [kb, nk), multiples of 3
-    if constexpr (SPLIT) {
+    const bool is_split = (int)blockIdx.x < sp.n_split;       // workgroup-uniform
+    if (is_split) {
         const int tt = blockIdx.x / sp.parts, part = blockIdx.x - tt * sp.parts;
         tile = sp.tile_base + tt;
         kb = 3 * (part * kpr / sp.parts);
         nk = 3 * ((part + 1) * kpr / sp.parts);
     } else {
-        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int nwg = gridDim.x - sp.n_split, bid = blockIdx.x - sp.n_split;
         const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r8 = nwg & 7;
         tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
     }
@@ -636,7 +639,7 @@ __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restri
     __syncthreads();                     // LDS becomes the epilogue slabs
     RPG_TRACE(3);
     const int ws = __builtin_amdgcn_readfirstlane(wave);       // wave-uniform by construction: scalar addressing below
-    if constexpr (SPLIT)
+    if (is_split)
         wino43_epilogue_partial(acc, lds + ws * (64 * 36), lane, (ws >> 1) * 32, (ws & 1) * 32,
                                 sp.partial + (size_t)blockIdx.x * (BMT8 * 4 * BN));
     else
@@ -984,35 +987,31 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
         // tiles a small fix-up kernel adds in k order.
         static bool attr8[64] = {};
         if (!attr8[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino43_conv8_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino43_conv8_kernel<true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino43_conv8_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
             attr8[dev] = true;
         }
         const long T = tm8 * tn;
-        const int S = num_cus(), nk = 3 * ((cin + BK - 1) / BK);
+        const int S = num_cus(), kpr = (cin + BK - 1) / BK, nk = 3 * kpr;
         executed = (double)T * nk * 48.0 * 8.0 * 4096.0;
         long t_main = T;
-        Split sp{0, 1, nullptr};
+        Split sp{0, 1, 0, nullptr};
         const long tail = T % S;
         if (g_wino_split && tail > 0) {
             int parts = (int)(S / tail);
-            if (parts > nk / 4) parts = nk / 4;
+            if (parts > kpr) parts = kpr;               // a part is at least one channel block (3 K steps)
+            if (parts > nk / 4 && nk / 4 >= 2) parts = nk / 4;
             if (parts >= 2) {
                 sp.partial = stream_scratch(s, (size_t)tail * parts * (BMT8 * 4 * BN) * sizeof(float));
-                if (sp.partial) { sp.parts = parts; t_main = T - tail; sp.tile_base = (int)t_main; }
+                if (sp.partial) { sp.parts = parts; t_main = T - tail; sp.tile_base = (int)t_main; sp.n_split = (int)(tail * parts); }
             }
         }
-        if (t_main > 0)
-            hipLaunchKernelGGL(wino43_conv8_kernel<false>, dim3((unsigned)t_main), dim3(NT8), LDS8_BYTES, s, x, u, h, w, cin,
-                               cout, tw, (int)M, ep, tn, sp);
-        if (t_main < T) {
-            const unsigned rem = (unsigned)(T - t_main);
-            hipLaunchKernelGGL(wino43_conv8_kernel<true>, dim3(rem * sp.parts), dim3(NT8), LDS8_BYTES, s, x, u, h, w, cin, cout,
-                               tw, (int)M, ep, tn, sp);
-            hipLaunchKernelGGL(wino43_fixup_kernel, dim3(rem * 32), dim3(256), 0, s, sp.partial, ep, (int)M, tw, w, cout, tn, sp);
-        }
+        // one launch: the split workgroups first, then the whole tiles
+        hipLaunchKernelGGL(wino43_conv8_kernel, dim3((unsigned)(sp.n_split + t_main)), dim3(NT8), LDS8_BYTES, s, x, u, h, w, cin,
+                           cout, tw, (int)M, ep, tn, sp);
+        if (sp.n_split)
+            hipLaunchKernelGGL(wino43_fixup_kernel, dim3((unsigned)(T - t_main) * 32), dim3(256), 0, s, sp.partial, ep, (int)M, tw, w,
+                               cout, tn, sp);
     } else {
         const int tm = (int)((M + BMT - 1) / BMT);
         executed = (double)tm * tn * (3 * ((cin + BK - 1) / BK)) * 48.0 * 4.0 * 4096.0;
