@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--bf16-bk", type=int, default=0, help="K step of the bf16 conv kernel (32|64; 0 = library default)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="rpg_set_tuning(KEY, VALUE) before the run, for A/B experiments (e.g. --tune 8=0: no Winograd split-K tail)")
+    ap.add_argument("--schedule", default="", help="explicit stream schedule g0:g1:slot,... (experiments; default: --streams equal groups)")
     ap.add_argument("--encoder-dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 = the headline configuration (configs[1]); bf16 = configs[2] (bf16 activations + MFMA conv)")
     return ap.parse_args()
@@ -170,6 +171,8 @@ def main():
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     model.hip_streams = args.streams
+    if args.schedule:
+        model.stream_schedule = [tuple(int(v) for v in part.split(":")) for part in args.schedule.split(",")]
     model.encoder_dtype = args.encoder_dtype
     model.gnn_dtype = args.gnn_dtype
     if args.bf16_bk:

@@ -114,6 +114,9 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         # and the parts run concurrently, which fills the tile-quantisation tails of one part's kernels with the other
         # part's work).  Needs the host-side slice table of relpose_gnn_amd.graph.Batch; other inputs use one stream.
         self.hip_streams = 2
+        # optional explicit schedule (experiments / tuning): [(first graph, last graph + 1, stream slot), ...] in issue order;
+        # groups on the same slot run one after the other.  None = `hip_streams` equal contiguous groups, one per stream.
+        self.stream_schedule: Optional[List[Tuple[int, int, int]]] = None
         self._streams: List[torch.cuda.Stream] = []
         self._enc = EncoderRunner()
         self._gnn_packed: Optional[List[torch.Tensor]] = None
@@ -261,7 +264,7 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         key = (n, e, d, feat.device)
         ent = self._gnn_ws.get(slot)
         if ent is None or ent[0] != key:
-            skew = (int(slot) % 7) * 132 * 1024 if isinstance(slot, int) else 0      # see resnet.EncoderRunner: de-aliases the slots
+            skew = ((slot[0] + 3 * slot[1]) % 7 if isinstance(slot, tuple) else int(slot) % 7) * 132 * 1024      # see resnet.EncoderRunner: de-aliases the slots
             raw = torch.empty(lib.rpg_gnn_workspace_bytes(n, e, d) + skew, dtype=torch.uint8, device=feat.device)
             ent = (key, raw[skew:])
             self._gnn_ws[slot] = ent
@@ -329,11 +332,26 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         if gs is None or len(gs[0]) < 2 * parts:
             return None
         nodes, edges = gs
+        if self.stream_schedule:
+            cn, ce = [0], [0]
+            for a, b in zip(nodes, edges):
+                cn.append(cn[-1] + a)
+                ce.append(ce[-1] + b)
+            out = []
+            covered = 0
+            for g0, g1, slot in self.stream_schedule:
+                if not (0 <= g0 < g1 <= len(nodes)) or not (0 <= slot < 8):
+                    raise ValueError("stream_schedule: groups must be non-empty ranges of graphs, slots 0..7")
+                out.append((cn[g0], cn[g1], ce[g0], ce[g1], slot))
+                covered += g1 - g0
+            if covered != len(nodes):
+                raise ValueError("stream_schedule must cover every graph of the batch exactly once")
+            return out
         out, g0, n0, e0 = [], 0, 0, 0
         for p in range(parts):
             g1 = len(nodes) * (p + 1) // parts
             n1, e1 = n0 + sum(nodes[g0:g1]), e0 + sum(edges[g0:g1])
-            out.append((n0, n1, e0, e1))
+            out.append((n0, n1, e0, e1, p))
             g0, n0, e0 = g1, n1, e1
         return out
 
@@ -408,7 +426,8 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         """Fast path (use_AP, no kNN / dropout / extra attention) on ``len(parts)`` concurrent streams."""
         dev = x.device
         n_total, e_total = x.size(0), edge_index.size(1)
-        while len(self._streams) < len(parts):
+        n_slots = 1 + max(p[4] for p in parts)
+        while len(self._streams) < n_slots:
             self._streams.append(torch.cuda.Stream(device=dev))
         cur = torch.cuda.current_stream()
         abs_pose = torch.empty((n_total, 6), dtype=torch.float32, device=dev)
@@ -417,15 +436,19 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         ready = torch.cuda.Event()
         ready.record(cur)
         base = edge_index.data_ptr()
-        for slot, (n0, n1, e0, e1) in enumerate(parts):
-            st = self._streams[slot]
+        for st in self._streams[:n_slots]:
             st.wait_event(ready)
+        for gi, (n0, n1, e0, e1, slot) in enumerate(parts):
+            st = self._streams[slot]
             with torch.cuda.stream(st):
-                feat = self._enc.run(self.feature_extractor.state_dict, "", x[n0:n1], slot=slot)
+                # workspaces are per (slot, position in the slot's queue): groups of a slot run in order, so they could share,
+                # but a different shape would re-allocate every call
+                wkey = (slot, gi)
+                feat = self._enc.run(self.feature_extractor.state_dict, "", x[n0:n1], slot=wkey)
                 self._gnn_call(lib, feat, base + 8 * e0, base + 8 * (e_total + e0), n0, n1 - n0, e1 - e0, abs_pose[n0:n1],
-                               rel_pose[e0:e1], None, None, status[slot:slot + 1], slot)
+                               rel_pose[e0:e1], None, None, status[slot:slot + 1], wkey)
                 feat.record_stream(st)
-        for st in self._streams[:len(parts)]:
+        for st in self._streams[:n_slots]:
             cur.wait_stream(st)
         self._publish_status()
         return abs_pose, rel_pose, edge_index

@@ -95,7 +95,7 @@ class EncoderRunner:
             nbytes = (lib.rpg_resnet_bf16_workspace_bytes if bf16 else lib.rpg_resnet_workspace_bytes)(n, h, w, planes_c)
             # concurrent stream slots get workspaces that start at different offsets within a 2-MiB window: torch hands
             # out 2-MiB-aligned blocks and identically laid-out workspaces would put both streams on the same HBM channels
-            skew = (int(slot) % 7) * 132 * 1024 if isinstance(slot, int) else 0
+            skew = ((slot[0] + 3 * slot[1]) % 7 if isinstance(slot, tuple) else int(slot) % 7) * 132 * 1024
             raw = torch.empty(nbytes + skew, dtype=torch.uint8, device=x.device)
             ent = (key, raw[skew:])
             self._ws[slot] = ent

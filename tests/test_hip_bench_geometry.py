@@ -88,7 +88,7 @@ def test_configs1_forward_as_benched_vs_oracle(dev):
     cum_n, cum_e = torch.arange(G + 1) * N, torch.arange(G + 1) * 56
     pyg = types.SimpleNamespace(x=data.x, edge_index=data.edge_index, edge_attr=None, batch=data.batch, num_graphs=G,
                                 _slice_dict={"x": cum_n, "edge_index": cum_e})
-    assert m._partition(pyg, G * N, G * 56) == [(0, 128, 0, 896), (128, 256, 896, 1792)]
+    assert m._partition(pyg, G * N, G * 56) == [(0, 128, 0, 896, 0), (128, 256, 896, 1792, 1)]
     ap, rp, _ = m(pyg)
     assert torch.equal(ap, a2) and torch.equal(rp, r2)
 

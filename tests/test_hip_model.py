@@ -331,6 +331,16 @@ def test_multi_stream_equals_single_stream(dev):
         assert ei is b.edge_index
     for a, r in outs[1:]:
         assert rel_err(a, outs[0][0]) < 1e-5 and rel_err(r, outs[0][1]) < 1e-5
+    # an explicit schedule: two groups queued on one stream beside a third group on another (PoseNetX_R2.stream_schedule)
+    m.hip_streams = 2
+    m.stream_schedule = [(0, 3, 0), (3, 5, 1), (5, 7, 1)]
+    a, r, _ = m(b)
+    m.stream_schedule = None
+    assert rel_err(a.cpu(), outs[0][0]) < 1e-5 and rel_err(r.cpu(), outs[0][1]) < 1e-5
+    with pytest.raises(ValueError):
+        m.stream_schedule = [(0, 3, 0), (3, 6, 1)]                 # does not cover the batch
+        m(b)
+    m.stream_schedule = None
     m.hip_streams = 2
     bad = Batch.from_data_list(graphs).to(dev)
     bad.edge_index[0, -1] = 0                      # last graph's edge pointing into the first graph

@@ -164,7 +164,7 @@ def test_stream_partition_from_pyg_batch_tables():
     assert PoseNetX_R2._graph_sizes(pyg2, n + 8, e) is None
     m = PoseNetX_R2(ResNet((1, 1, 1, 1), (8, 16, 32, 64)), droprate=0.0, pretrained=False, feat_dim=64, edge_feat_dim=64,
                     node_dim=64, use_gnn=True)
-    assert m._partition(pyg2, n, e) == [(0, 24, 0, 168), (24, 48, 168, 336)]
+    assert m._partition(pyg2, n, e) == [(0, 24, 0, 168, 0), (24, 48, 168, 336, 1)]
     assert m._partition(types.SimpleNamespace(x=ref.x[:8], edge_index=ref.edge_index[:, :56], batch=ref.batch[:8],
                                               num_graphs=1), 8, 56) is None
 
