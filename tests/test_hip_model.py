@@ -314,6 +314,36 @@ def test_eval_harness_end_to_end(dev):
     assert res.t_loss.shape == (7,) and np.isfinite(res.summary()).all()
 
 
+def test_eval_harness_with_the_reference_default_knn(dev):
+    """The reference's default flags (`--knn 4`, test.py:308): the model rebuilds the graph from the encoder features
+    (posenet.py:1047-1048) and eval_RP post-processes the edge list the MODEL returns.  evaluate_stream (micro-batches of 3
+    graphs, model-built edge lists cut per graph) == oracle forward with knn=4 on every graph alone + oracle post-processing."""
+    import relpose_gnn_amd.synth as S
+    from oracle import posenet_ref as O
+    from relpose_gnn_amd import evaluate as E
+    from relpose_gnn_amd.graph import Data, fc_edge_index
+    from relpose_gnn_amd.posenet import PoseNetX_R2
+    from relpose_gnn_amd.resnet import ResNet
+    planes, blocks, D = (8, 16, 32, 64), (1, 1, 1, 1), 64
+    m = PoseNetX_R2(ResNet(blocks, planes), droprate=0.0, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D,
+                    input_img_height=32, use_gnn=True, knn=4, use_AP=True, gnn_recursion=2)
+    sd = S.synth_state_dict(S.posenet_r2_param_shapes(D, D, D, planes, blocks), seed=1)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    graphs, ref_pred = [], []
+    pm, ps = np.array([0.5, -1.0, 2.0]), np.array([2.0, 3.0, 0.5])
+    for i in range(7):
+        x = S.synth_images(8, 32, 40, seed=400 + i)
+        y = S.hash_normal(f"evalknn.y{i}", (8, 6), 0.3)
+        graphs.append(Data(x=x, edge_index=fc_edge_index(8), y=y))
+        _, rel, ei = O.posenet_forward(sd, x, fc_edge_index(8), 32, 2, knn=4, batch=torch.zeros(8, dtype=torch.int64))
+        assert ei.shape == (2, 32)                                              # 8 nodes x 4 neighbours
+        raw = O.query_pose_from_relative(rel.numpy().astype(np.float64), y.numpy().astype(np.float64), ei.numpy())
+        ref_pred.append(np.hstack((raw[:3] * ps + pm, O.qexp(raw[3:]))))
+    res = E.evaluate_stream(m, graphs, dev, micro_batch=3, pose_m=pm, pose_s=ps)
+    assert np.allclose(res.pred_poses, np.stack(ref_pred), atol=2e-4, rtol=1e-4)
+
+
 def test_multi_stream_equals_single_stream(dev):
     """The batch cut at graph boundaries over 1 / 2 / 3 HIP streams gives the same poses (ragged graph sizes: 8, 4, 8,
     8, 4, 8, 8 nodes) and still flags an edge that leaves its graph."""
