@@ -12,11 +12,12 @@
 //     with v_mfma_f32_32x32x2_f32 (exact fp32): K = 3*7*7 = 147 taps = 74 pairs, a wave keeps ALL 74 x 2 weight operands
 //     in registers for its whole life (the kernel is persistent: one workgroup per CU walks the tiles), so the K loop is
 //     one ds_read_b32 (the A operand, straight from the patch: the two k-slices of an MFMA are two taps a constant
-//     distance apart, so half-wave 1 reads at base + delta) and two MFMAs, with no barrier and no staging;
+//     distance apart, so half-wave 1 reads at base + delta) and two MFMAs, with no barrier and no staging; a fragment is
+//     4 x 8 pixels, so that a lane ends up with a 4 x 4 pixel block of its channel;
 //   * the BatchNorm scale is folded into the weight operands at pack time, its shift and the ReLU are applied to the
-//     accumulators (a lane holds one channel), and every convolution output is folded into the <= 4 pooled cells it
-//     belongs to with an LDS atomic max (values are >= 0 after the ReLU, so the unsigned-integer max of the bit patterns
-//     is the float max and 0 is the identity); which cells a pixel feeds is a small per-tile table in LDS;
+//     accumulators (a lane holds one channel), the lane's 4 x 4 block is max-reduced in registers into the <= 9 pooled
+//     cells it touches, and those partial maxima are combined across lanes / fragments with LDS atomic max (values are >= 0
+//     after the ReLU, so the unsigned-integer max of the bit patterns is the float max and 0 is the identity);
 //   * the pooled tile (a contiguous NHWC block per pooled row) is flushed with 16-byte stores.
 // The convolution rows / columns on a tile border are computed by both neighbours (9/8 x 113/112 of the MACs at 224x224);
 // nothing but the input (154 MB at 256 images) and the pooled output (205 MB) touches HBM.
@@ -34,7 +35,7 @@ constexpr int TWP_MAX = 56;                // pooled columns per tile
 constexpr int PITCH = 4 * TWP_MAX + 8;     // 232 floats per patch row (4 TWp + 7 used)
 constexpr int KP = 74;                     // tap pairs (147 taps + 1 zero)
 constexpr int NF = 2;                      // 32-channel fragments (64 output channels)
-constexpr int NFRAG_MAX = (CR * (2 * TWP_MAX + 1) + 31) / 32;     // 32 fragments of 32 pixels
+constexpr int NFRAG_MAX = (CR * (2 * TWP_MAX + 1) + 31) / 32;     // 32 fragments of 32 pixels (28 blocks + 4 rows of 32 at TWp = 56)
 constexpr int PATCH_FLOATS = 3 * IR * PITCH;                      // 16008
 constexpr int POOL_FLOATS = (PH * TWP_MAX + 1) * 64;              // 224 cells + 1 trash cell
 constexpr int TAB_DWORDS = NFRAG_MAX * 32 * 4;                    // per convolution pixel: byte offsets of its <= 4 pooled cells
@@ -47,6 +48,7 @@ struct StemArgs {
     float* out;            // [N][Hp][Wp][64]
     int N, H, W, Hc, Wc, Hp, Wp;
     int TWp, tiles_x, tiles_y, RW, nfrag, total_tiles;
+    int nbx, nblk, ncl;    // 4 x 8-pixel block fragments: nbx per block row, nblk = 2 nbx in all; ncl = RW - 8 nbx leftover columns
 };
 
 // float offset of tap (c, kh, kw) inside the patch, relative to a pixel's top-left tap
@@ -90,35 +92,6 @@ __global__ __launch_bounds__(ST_NT) void stem_pool_kernel(StemArgs a) {
     // patch staging: thread t copies column t & 255 of patch rows (t >> 8) + 2 u, u = 0 .. 34 (69 rows = 3 planes x 23)
     const int pcol = tid & 255, prow0 = __builtin_amdgcn_readfirstlane(tid >> 8);
     constexpr int NROW = 3 * IR, NPV = (NROW + 1) / 2;
-    float pv[NPV];
-    // patch of a tile -> registers, zero outside the image.  Branch-free per lane (a row outside the image is a uniform
-    // skip, a column outside it a clamped address + select), so all 35 loads of a thread are in flight together.
-    auto fetch_patch = [&](int t) {
-        const int n = t / (a.tiles_y * a.tiles_x);
-        const int tr = t - n * (a.tiles_y * a.tiles_x);
-        const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
-        const int iy0 = 2 * (2 * ty * PH - 1) - 3, ix0 = 2 * (2 * tx * a.TWp - 1) - 3;
-        const float* img = a.x + (size_t)n * 3 * a.H * a.W;
-        const int ix = ix0 + pcol;
-        const int ixc = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
-        // every load is unconditional on a clamped address (rows and columns outside the image are zeroed where pv is
-        // consumed): one load instruction with a scalar row base per element, no branches, nothing waits here
-#pragma unroll
-        for (int u = 0; u < NPV; ++u) {
-            int rr = prow0 + 2 * u;                              // wave-uniform: c * IR + r
-            rr = rr < NROW ? rr : NROW - 1;
-            const int c = rr / IR, r = rr - c * IR;
-            int iy = iy0 + r;
-            iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
-#ifndef ST_NO_PATCH
-            pv[u] = img[((size_t)c * a.H + iy) * a.W + ixc];
-#else
-            pv[u] = 1.f;
-#endif
-        }
-    };
-    if ((int)blockIdx.x < a.total_tiles) fetch_patch(blockIdx.x);
-
     for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
         const int n = tile / (a.tiles_y * a.tiles_x);
         const int tr = tile - n * (a.tiles_y * a.tiles_x);
@@ -127,14 +100,44 @@ __global__ __launch_bounds__(ST_NT) void stem_pool_kernel(StemArgs a) {
         const int cy0 = 2 * P0 - 1, cx0 = 2 * Q0 - 1;            // first convolution row / column of the tile
         const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;          // first input row / column of the patch
         const int npix = CR * a.RW;
-        // ---- phase 1: clear the pooled tile, build the pixel -> cell table, write the prefetched patch to LDS
+        // ---- phase 1: stage the input patch (zero outside the image), clear the pooled tile, build the leftover-pixel table.
+        // The loads come first and are unconditional on clamped addresses (rows / columns outside the image are zeroed when
+        // the value is written to LDS), so all 35 of a thread are in flight together behind the table arithmetic.  (Keeping
+        // them in flight across the previous tile's MFMA phase instead was measured: no gain, and 35 more live registers.)
         {
+            float pv[NPV];
+            {
+                const float* img = a.x + (size_t)n * 3 * a.H * a.W;
+                const int ix = ix0 + pcol;
+                const int ixc = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+#pragma unroll
+                for (int u = 0; u < NPV; ++u) {
+                    int rr = prow0 + 2 * u;                      // wave-uniform: c * IR + r
+                    rr = rr < NROW ? rr : NROW - 1;
+                    const int c = rr / IR, r = rr - c * IR;
+                    int iy = iy0 + r;
+                    iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+#ifndef ST_NO_PATCH
+                    pv[u] = img[((size_t)c * a.H + iy) * a.W + ixc];
+#else
+                    pv[u] = 1.f;
+#endif
+                }
+            }
             for (int i = tid; i < (PH * a.TWp + 1) * 16; i += ST_NT) reinterpret_cast<uint4*>(pooled)[i] = make_uint4(0u, 0u, 0u, 0u);
-            for (int p = tid; p < a.nfrag * 32; p += ST_NT) {
-                const int ey = p / a.RW, ex = p - ey * a.RW;
+            // leftover pixels (the 9th convolution row, then the columns right of the last block, rows 0..7): pixel -> cells
+            for (int l = tid; l < (a.nfrag - a.nblk) * 32; l += ST_NT) {
+                int ey = CR - 1, ex = l;
+                bool in = l < a.RW;
+                if (!in && a.ncl > 0) {
+                    const int l2 = l - a.RW;
+                    ey = l2 / a.ncl;
+                    ex = 8 * a.nbx + (l2 - ey * a.ncl);
+                    in = ey < CR - 1;
+                }
                 const int cy = cy0 + ey, cx = cx0 + ex;
                 unsigned c4[4] = {trash, trash, trash, trash};
-                if (p < npix && (unsigned)cy < (unsigned)a.Hc && (unsigned)cx < (unsigned)a.Wc) {
+                if (in && (unsigned)cy < (unsigned)a.Hc && (unsigned)cx < (unsigned)a.Wc) {
                     // pooled rows r with 2r-1 <= cy <= 2r+1 (one for even cy, two for odd), tile-local; same for columns
                     const int r0 = (cy >> 1) - P0, r1 = ((cy + 1) >> 1) - P0, q0 = (cx >> 1) - Q0, q1 = ((cx + 1) >> 1) - Q0;
                     const bool r0v = (unsigned)r0 < (unsigned)PH && P0 + r0 < a.Hp, r1v = r1 != r0 && (unsigned)r1 < (unsigned)PH && P0 + r1 < a.Hp;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(ST_NT) void stem_pool_kernel(StemArgs a) {
                     if (r1v && q0v) c4[2] = (unsigned)(r1 * a.TWp + q0) * 256u;
                     if (r1v && q1v) c4[3] = (unsigned)(r1 * a.TWp + q1) * 256u;
                 }
-                tab[p] = make_uint4(c4[0], c4[1], c4[2], c4[3]);
+                tab[l] = make_uint4(c4[0], c4[1], c4[2], c4[3]);
             }
             if (pcol < PITCH) {
                 const bool col_ok = pcol < 4 * a.TWp + 7 && (unsigned)(ix0 + pcol) < (unsigned)a.W;
@@ -158,14 +161,29 @@ __global__ __launch_bounds__(ST_NT) void stem_pool_kernel(StemArgs a) {
             }
         }
         __syncthreads();
-        // the next tile's patch travels from HBM to registers while this tile's MFMAs run (all workgroups stage at about the
-        // same time: done in the open, the 228 MB of patches were a bandwidth-bound burst of ~80 us per launch)
-        if (tile + (int)gridDim.x < a.total_tiles) fetch_patch(tile + gridDim.x);
-        // ---- phase 2: 32 convolution pixels x 64 channels per fragment, fragments dealt round-robin to the waves
+        // ---- phase 2: 32 convolution pixels x 64 channels per fragment, fragments dealt round-robin to the waves.
+        // Fragments 0 .. nblk-1 are 4 rows x 8 columns of convolution pixels: in the MFMA result a lane then holds a 4 x 4
+        // pixel block of its channel (rows = register quads, columns 4 h .. 4 h + 3), and since a tile starts on odd
+        // convolution coordinates (2 P0 - 1, 2 Q0 - 1) that block touches three pooled rows x three pooled columns: it is reduced
+        // in registers and costs <= 9 LDS atomics per channel half instead of 36.  The remaining pixels (9th row, right-hand
+        // columns) go 32 in a row through the per-pixel table.
         for (int f = wave; f < a.nfrag; f += ST_NT / 64) {
-            int p = f * 32 + (lane & 31);
-            p = p < npix ? p : npix - 1;
-            const int oy = p / a.RW, ox = p - oy * a.RW;
+            const bool blk = f < a.nblk;
+            int oy, ox, by = 0, bx = 0;
+            if (blk) {
+                by = f / a.nbx; bx = f - by * a.nbx;
+                oy = 4 * by + ((lane & 31) >> 3);
+                ox = 8 * bx + (lane & 7);
+            } else {
+                const int l = (f - a.nblk) * 32 + (lane & 31);
+                oy = CR - 1; ox = l;
+                if (l >= a.RW) {
+                    const int l2 = l - a.RW;
+                    oy = a.ncl > 0 ? l2 / a.ncl : CR;
+                    ox = 8 * a.nbx + (l2 - oy * a.ncl);
+                    if (oy >= CR - 1) { oy = 0; ox = 0; }        // padding lanes of the last fragment: any valid address
+                }
+            }
             const float* q = patch + (2 * oy * PITCH + 2 * ox);
             const float* q0 = q + (h ? 1 : 0);                   // half-wave 1 holds the second tap of a pair: next column,
             const float* q1 = q + (h ? PITCH : 0);               // next row,
@@ -188,31 +206,90 @@ __global__ __launch_bounds__(ST_NT) void stem_pool_kernel(StemArgs a) {
 #endif
                 }
             }
-            // + shift, ReLU, then fold every convolution output into the pooled cells it belongs to (LDS atomic max on the
+            // + shift, ReLU, then fold the convolution outputs into the pooled cells they belong to (LDS atomic max on the
             // bit patterns: exact for non-negative floats)
-            const int p0 = f * 32 + 4 * h;
 #ifdef ST_NO_EPI
             if (a.N == -5)
 #endif
+            if (blk) {
+                // element e of an accumulator = pixel (row e >> 2, column 4 h + (e & 3)) of the block
+                const int cyb = cy0 + 4 * by, cxs = cx0 + 8 * bx + 4 * h;
+                bool rok[4], cok[4];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const uint4 cells = tab[p0 + (e & 3) + 8 * (e >> 2)];          // uniform over a half-wave: broadcast read
-                const unsigned v0 = __float_as_uint(fmaxf(acc[0][e] + sh[0], 0.f));
-                const unsigned v1 = __float_as_uint(fmaxf(acc[1][e] + sh[1], 0.f));
-                const unsigned co[4] = {cells.x, cells.y, cells.z, cells.w};
+                for (int t = 0; t < 4; ++t) {
+                    rok[t] = (unsigned)(cyb + t) < (unsigned)a.Hc;
+                    cok[t] = (unsigned)(cxs + t) < (unsigned)a.Wc;
+                }
+                // The block starts on odd convolution coordinates (row 2 r - 1 with r = P0 + 2 by, column 2 q - 1 with q = Q0 + 4 bx
+                // + 2 h), so its rows {0}, {0,1,2}, {2,3} belong to pooled rows r-1, r, r+1 and its columns likewise to q-1, q,
+                // q+1: nine cells, reduced in registers (the missing rows / columns of a cell come from the neighbouring blocks
+                // through the same atomics).
+                const int ra = 2 * by, qa = 4 * bx + 2 * h;
+                unsigned cell[3][3];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    // a pixel feeds 1, 2 or 4 cells by the parity of its row / column, the same for both half-waves except
-                    // across a row end: skip the LDS atomics (~8 LDS cycles each, the LDS is shared by the CU) when no lane
-                    // has a target
-                    if (k > 0 && __builtin_amdgcn_ballot_w64(co[k] != trash) == 0) continue;
-                    unsigned* cell = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(pooled) + (co[k] + lane_b));
+                for (int ri = 0; ri < 3; ++ri)
+#pragma unroll
+                    for (int qi = 0; qi < 3; ++qi) {
+                        const int r = ra - 1 + ri, qq = qa - 1 + qi;
+                        const bool ok = (unsigned)r < (unsigned)PH && P0 + r < a.Hp && (unsigned)qq < (unsigned)a.TWp && Q0 + qq < a.Wp;
+                        cell[ri][qi] = (ok ? (unsigned)(r * a.TWp + qq) * 256u : trash) + lane_b;
+                    }
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                    float c[4][3];                               // per block row: column 0, max over columns 0-2, max over 2-3
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) {
+                        float v[4];
+#pragma unroll
+                        for (int xx = 0; xx < 4; ++xx) {
+                            const float t = fmaxf(acc[nf][4 * y + xx] + sh[nf], 0.f);
+                            v[xx] = rok[y] && cok[xx] ? t : 0.f;  // outside the image: 0, the identity of max over values >= 0
+                        }
+                        c[y][0] = v[0];
+                        c[y][1] = fmaxf(fmaxf(v[0], v[1]), v[2]);
+                        c[y][2] = fmaxf(v[2], v[3]);
+                    }
+#pragma unroll
+                    for (int qi = 0; qi < 3; ++qi) {
+                        const float m0 = c[0][qi];                                           // pooled row r - 1: block row 0
+                        const float m1 = fmaxf(fmaxf(c[0][qi], c[1][qi]), c[2][qi]);         // pooled row r: rows 0-2
+                        const float m2 = fmaxf(c[2][qi], c[3][qi]);                          // pooled row r + 1: rows 2-3
+                        const float m[3] = {m0, m1, m2};
+#pragma unroll
+                        for (int ri = 0; ri < 3; ++ri) {
+                            // the cells of row r - 1 / column q - 1 exist only away from the tile's top / left edge: skip the
+                            // atomic when no lane has a target
+                            if ((ri == 0 || qi == 0) && __builtin_amdgcn_ballot_w64(cell[ri][qi] != trash + lane_b) == 0) continue;
 #ifndef ST_NO_ATOMICS
-                    atomicMax(cell, v0);
-                    atomicMax(cell + 32, v1);
+                            atomicMax(reinterpret_cast<unsigned*>(reinterpret_cast<char*>(pooled) + cell[ri][qi]) + 32 * nf,
+                                      __float_as_uint(m[ri]));
 #else
-                    asm volatile("" ::"v"(cell), "v"(v0), "v"(v1));
+                            asm volatile("" ::"v"(cell[ri][qi]), "v"(m[ri]));
 #endif
+                        }
+                    }
+                }
+            } else {
+                const int l0 = (f - a.nblk) * 32 + 4 * h;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint4 cells = tab[l0 + (e & 3) + 8 * (e >> 2)];      // uniform over a half-wave: broadcast read
+                    const unsigned v0 = __float_as_uint(fmaxf(acc[0][e] + sh[0], 0.f));
+                    const unsigned v1 = __float_as_uint(fmaxf(acc[1][e] + sh[1], 0.f));
+                    const unsigned co[4] = {cells.x, cells.y, cells.z, cells.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        // a pixel feeds 1, 2 or 4 cells by the parity of its row / column: skip the LDS atomics (~8 LDS cycles
+                        // each, the LDS is shared by the CU) when no lane has a target
+                        if (k > 0 && __builtin_amdgcn_ballot_w64(co[k] != trash) == 0) continue;
+                        unsigned* cellp = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(pooled) + (co[k] + lane_b));
+#ifndef ST_NO_ATOMICS
+                        atomicMax(cellp, v0);
+                        atomicMax(cellp + 32, v1);
+#else
+                        asm volatile("" ::"v"(cellp), "v"(v0), "v"(v1));
+#endif
+                    }
                 }
             }
         }
@@ -249,7 +326,10 @@ int launch_stem_pool(const float* x_nchw, const float* wpack, const float* shift
     a.TWp = (a.Wp + a.tiles_x - 1) / a.tiles_x;
     a.tiles_y = (a.Hp + PH - 1) / PH;
     a.RW = 2 * a.TWp + 1;
-    a.nfrag = (CR * a.RW + 31) / 32;
+    a.nbx = a.RW / 8;                          // block fragments: rows 0..7 x columns 0..8 nbx - 1
+    a.nblk = 2 * a.nbx;
+    a.ncl = a.RW - 8 * a.nbx;                  // leftover columns (1..7): with the 9th row they go through 1 x 32 fragments
+    a.nfrag = a.nblk + (a.RW + 8 * a.ncl + 31) / 32;
     const long total = (long)n * a.tiles_y * a.tiles_x;
     if (total >= (1L << 31) || (long)n * 3 * h * w >= (1L << 40)) return RPG_ERR_BAD_ARG;
     a.total_tiles = (int)total;
