@@ -54,14 +54,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    objs = []
-    for src in SOURCES:
+    from concurrent.futures import ThreadPoolExecutor
+
+    def compile_one(src):
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:      # the translation units are independent
+        objs = list(pool.map(compile_one, SOURCES))
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp", *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
