@@ -206,7 +206,8 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         return self._status
 
     def _raise_bad_edges(self, bad: int):
-        self._status.zero_()
+        self._status.zero_()                      # (stream-ordered: after every forward issued so far)
+        self._status_host.zero_()                 # the mirror too, or a look without waiting would report it again
         self._status_pending = False
         raise IndexError(f"edge_index has {bad} edge(s) with a node id outside its graph group / [0, N) "
                          "(detected on the device; with index_check='deferred' this refers to an EARLIER forward call)")
