@@ -160,10 +160,128 @@ __device__ __forceinline__ void wino43_epilogue(const f32x16 (&acc)[P], float* s
     }
 }
 
+// The same epilogue with a smaller register footprint, for the persistent kernel (which keeps the NEXT tile's fetch state
+// and in-flight loads alive across it): one half (two of the four pixel columns) at a time -- residual reads of a half
+// are issued before that half's output transform, those of the second half as soon as the first half's transform
+// registers are free -- and the second half's offsets are rebuilt from the first half's + a validity mask.  mid() runs
+// after the second output transform, when the accumulators are dead (the persistent kernel re-issues the next tile's
+// K-step-1 loads there).
+template <bool RES, class Mid>
+__device__ __forceinline__ void wino43_epilogue_lean_body(const f32x16 (&acc)[P], float* slab, int lane, int mw0, int nw0, int M,
+                                                          int Tw, int W, int Cout, const Epi& ep, Mid mid) {
+    constexpr int EP = 32 + 4;
+    constexpr unsigned OOB = 0x80000000u;
+    const int c4 = lane & 7, pr = lane >> 3;
+    const int nb = nw0 + 4 * c4;
+    const bool n_ok = nb < Cout;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
+    if (n_ok && ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + nb);
+    if (n_ok && ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + nb);
+    const int t_first = mw0 / Tw;
+    const size_t row0 = (size_t)t_first * W * Cout;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ep.out + row0, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(ep.residual ? ep.residual + row0 : ep.out + row0), 0, 0x7fffffff, 0x00020000);
+    const int step_t = 4 / Tw, step_tw = 4 % Tw;
+    int mt = mw0 + (pr >> 1);
+    int trel = mt / Tw - t_first, tw = mt % Tw;
+    unsigned voff[8], ok2 = 0;             // first-half offsets; bit it of ok2: the second half's pixel column exists
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int wo = 4 * tw + (pr & 1);
+        const bool ok = n_ok && mt < M;
+        voff[it] = ok && wo < W ? 4u * (unsigned)((trel * W + wo) * Cout + nb) : OOB;
+        if (ok && wo + 2 < W) ok2 |= 1u << it;
+        mt += 4;
+        trel += step_t;
+        tw += step_tw;
+        if (tw >= Tw) { tw -= Tw; ++trel; }
+    }
+    const unsigned half_b = 8u * (unsigned)Cout;
+    auto off = [&](int half, int it) -> unsigned {
+        return half == 0 ? voff[it] : ((ok2 >> it) & 1u) ? voff[it] + half_b : OOB;
+    };
+    int relu_i = ep.relu;                               // opaque: hoisted out of the caller's tile loop, the select below
+    asm volatile("" : "+s"(relu_i));                     // became a VGPR that was spilled around the K loop
+    const float floor_v = relu_i ? 0.f : -INFINITY;
+    float4 rs[2][8];
+    auto load_res = [&](int half) {
+        if (RES) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                rs[half][it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, off(half, it), 0, 0));
+        }
+    };
+    auto transform_to_slab = [&](int half) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = 2 * q;
+            const f32x2 m1 = {acc[1][e], acc[1][e + 1]}, m2 = {acc[2][e], acc[2][e + 1]};
+            const f32x2 m3 = {acc[3][e], acc[3][e + 1]}, m4 = {acc[4][e], acc[4][e + 1]};
+            f32x2 ya, yb;
+            if (half == 0) {
+                const f32x2 m0 = {acc[0][e], acc[0][e + 1]};
+                const f32x2 d34 = m3 - m4;
+                ya = (m0 + (m1 + m2)) + (m3 + m4);
+                yb = (m1 - m2) + (d34 + d34);
+            } else {
+                const f32x2 m5 = {acc[5][e], acc[5][e + 1]};
+                const f32x2 d34 = m3 - m4, u = d34 + d34;
+                ya = (m1 + m2) + 4.f * (m3 + m4);
+                yb = ((m1 - m2) + 4.f * u) + m5;
+            }
+            const int trow = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            float* sp = slab + (2 * trow) * EP + (lane & 31);
+            sp[0] = ya.x;
+            sp[EP] = yb.x;
+            sp[2 * EP] = ya.y;
+            sp[3 * EP] = yb.y;
+        }
+    };
+    auto finish = [&](int half) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int prow = pr + 8 * it;
+            const float4 v = *reinterpret_cast<const float4*>(&slab[prow * EP + 4 * c4]);
+            f32x2 o0 = f32x2{v.x, v.y} * f32x2{sc.x, sc.y} + f32x2{sh.x, sh.y};
+            f32x2 o1 = f32x2{v.z, v.w} * f32x2{sc.z, sc.w} + f32x2{sh.z, sh.w};
+            if (RES) {                     // (without a residual nothing waits on memory here: zero-filling rs[] instead made
+                o0 += f32x2{rs[half][it].x, rs[half][it].y};       // the compiler wait for ALL outstanding stores and loads
+                o1 += f32x2{rs[half][it].z, rs[half][it].w};       // before overwriting registers they might still target)
+            }
+            const float4 yv = make_float4(fmaxf(o0.x, floor_v), fmaxf(o0.y, floor_v), fmaxf(o1.x, floor_v), fmaxf(o1.y, floor_v));
+#ifdef RPG_ABL_NOSTORE                     // ablation (tools/probes/wino_ablate.sh): only a value that never occurs is stored
+            if (yv.x == 1234.5678f)
+#endif
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yv), ro, off(half, it), 0, 0);
+        }
+    };
+    load_res(0);
+    transform_to_slab(0);
+    __builtin_amdgcn_wave_barrier();
+    finish(0);
+    load_res(1);
+    __builtin_amdgcn_wave_barrier();
+    transform_to_slab(1);
+    mid();                                 // the caller's loads for its next tile: the accumulators are dead from here on
+    __builtin_amdgcn_wave_barrier();
+    finish(1);
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <class Mid>
+__device__ __forceinline__ void wino43_epilogue_lean(const f32x16 (&acc)[P], float* slab, int lane, int mw0, int nw0, int M,
+                                                     int Tw, int W, int Cout, const Epi& ep, Mid mid) {
+    if (ep.residual) wino43_epilogue_lean_body<true>(acc, slab, lane, mw0, nw0, M, Tw, W, Cout, ep, mid);
+    else wino43_epilogue_lean_body<false>(acc, slab, lane, mw0, nw0, M, Tw, W, Cout, ep, mid);
+}
+
 // Split-K variant: the wave's raw output-transformed tile goes to dst[512 px][64 ch] of its workgroup's slab
 // (px = 4 * tile-in-workgroup + pixel column); no masking, the fix-up kernel knows what is valid.
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+template <class Mid = NoMid>
 __device__ __forceinline__ void wino43_epilogue_partial(const f32x16 (&acc)[P], float* slab, int lane, int mw, int nw,
-                                                        float* __restrict__ dst) {
+                                                        float* __restrict__ dst, Mid mid = Mid()) {
     constexpr int EP = 32 + 4;
     const int c4 = lane & 7, pr = lane >> 3;
 #pragma unroll
@@ -183,6 +301,7 @@ __device__ __forceinline__ void wino43_epilogue_partial(const f32x16 (&acc)[P], 
             slab[(2 * trow) * EP + (lane & 31)] = ya;
             slab[(2 * trow + 1) * EP + (lane & 31)] = yb;
         }
+        if (half == 1) mid();                                           // the accumulators are dead from here on
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -651,6 +770,253 @@ __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The persistent form of the 8-wave kernel (round 2): one workgroup per CU walks a list of work items -- item =
+// blockIdx.x + i * gridDim.x over [split-K parts | whole tiles], same item -> tile mapping as above -- and the load /
+// stage pipeline runs ACROSS items: during the last two K steps of an item the buffer loads already fetch steps 0 and 1 of
+// the next item, the last step stages the next item's step 0 into LDS image 0, and the epilogue uses image 1 (the one the
+// last step read) for its slabs.  What that removes per tile: the cold prologue (address set-up, one exposed HBM round
+// trip, first stage + barrier: 6.5-10.7 k cycles, profiles/r1_wino43_phase_cycles.txt) and the gap between a workgroup's
+// exit and its successor's first instruction on the CU (one 144-KB-LDS workgroup per CU: the dispatcher cannot overlap
+// them; SQ_BUSY_CU_CYCLES showed CUs without any wave 10-11 % of a layer-1/2 launch against 5 % on the one-round layers
+// 3-4).  What stays: the address set-up of the next item (inside the rarely taken branch of fetch_next, ~1.5 k cycles of
+// VALU) and the epilogue (its registers are the reason for wino43_epilogue_lean: the next item's 9 loads in flight and its
+// offsets stay live across it).  Requirements (else the launcher takes the kernel above): Cin % 32 == 0 -- every item is
+// then a multiple of 6 K steps, so LDS image and kernel-row phase are compile-time constants across items.
+__global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restrict__ x, const float* __restrict__ U, int H,
+                                                           int W, int Cin, int Cout, int Tw, int M, Epi ep, int tiles_n,
+                                                           Split sp, int n_items) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int K = 3 * Cin;
+    const int kpr = Cin / BK;                          // channel blocks per kernel row (even)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int row = tid >> 2, slot = tid & 3;
+    const int brow = row & 63, bhalf = tid >> 8;
+    const size_t img_floats = (size_t)H * W * Cin;
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, 0x7fffffff, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned ustride_b = (unsigned)Cout * K * 4u;
+    const unsigned row_b = 4u * (unsigned)(W * Cin), krow_b = 4u * (unsigned)Cin;
+
+    // ---- fetch-side state: the item whose K steps the buffer loads are walking (up to two steps ahead of the MFMAs)
+    int f_item = blockIdx.x, f_m0 = 0, f_n0 = 0, f_kb = 0, f_nk = 0, f_kt = 0, f_c0 = 0;
+    const float* f_base = x;
+    unsigned va3[3][P], vb_eff;
+    auto decode = [&]() {                 // fetch state of item f_item (everything out of range when there is none)
+        asm volatile("" ::: "memory");
+        int tid_d = tid;                  // opaque: keeps the lane-dependent part of this out of registers between calls
+        asm volatile("" : "+v"(tid_d));
+        const int row = tid_d >> 2, slot = tid_d & 3, brow = row & 63, bhalf = tid_d >> 8;
+        const bool valid = f_item < n_items;
+        int tile, kb = 0, nk = 3 * kpr;
+        if (f_item < sp.n_split) {
+            const int tt = f_item / sp.parts, part = f_item - tt * sp.parts;
+            tile = sp.tile_base + tt;
+            kb = 6 * (part * (kpr >> 1) / sp.parts);
+            nk = 6 * ((part + 1) * (kpr >> 1) / sp.parts);
+        } else {
+            const int nwg = n_items - sp.n_split, bid = f_item - sp.n_split;
+            const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r8 = nwg & 7;
+            tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+        }
+        f_m0 = (tile / tiles_n) * BMT8;
+        f_n0 = (tile - (tile / tiles_n) * tiles_n) * BN;
+        const int n_first = (f_m0 / Tw) / H;
+        f_base = x + n_first * img_floats - (size_t)W * Cin;
+        const int m = f_m0 + row;
+        int img_off = 0, ho = 0, wi0 = -(1 << 24);
+        unsigned rowbits = 0;
+        if (valid && m < M) {
+            const int t = m / Tw;
+            const int tw = m - t * Tw;
+            const int n = t / H;
+            ho = t - n * H;
+            img_off = (n - n_first) * (int)img_floats;
+            wi0 = 4 * tw - 1;
+            rowbits = (ho > 0 ? 1u : 0u) | 2u | (ho < H - 1 ? 4u : 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int wi = wi0 + j;
+            const unsigned o = (unsigned)wi < (unsigned)W ? 4u * (unsigned)(img_off + (ho * W + wi) * Cin + 4 * slot) : OOB;
+            // Kernel row 1 stays switched off until fix_row1(): the loads of the new item's K step 1 that the last K step
+            // of the current item would issue are skipped that way (an out-of-range offset costs no memory access) -- their
+            // registers are needed by the epilogue, which issues them itself (refetch) once the accumulators are dead.
+            va3[0][j] = (rowbits & 1u) ? o : OOB;
+            va3[1][j] = OOB;
+            va3[2][j] = (rowbits & 4u) ? o : OOB;
+        }
+        vb_eff = valid && f_n0 + brow < Cout ? 4u * (unsigned)((f_n0 + brow) * K + 4 * slot) + 3u * bhalf * ustride_b : OOB;
+        f_kb = kb;
+        f_kt = kb;
+        f_nk = valid ? nk : 0x3fffffff;   // no item: never advance again
+        f_c0 = (kb / 3) * BK;
+    };
+    // row ho exists whenever the tile does, and H >= 2 (launcher) makes one of its neighbours exist too: its offsets are
+    // the smaller (= valid, OOB is the largest unsigned value in use) of the two neighbours' offsets
+    auto fix_row1 = [&]() {
+#pragma unroll
+        for (int j = 0; j < P; ++j) va3[1][j] = va3[0][j] < va3[2][j] ? va3[0][j] : va3[2][j];
+    };
+    decode();
+    fix_row1();
+
+    float4 d[P], ub[3];
+    auto fetch_one = [&](int i, int kh) {
+        if (i < P) {
+            const __amdgpu_buffer_rsrc_t ra =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f_base), 0, 0x7fffffff, 0x00020000);
+            const unsigned sa = (unsigned)kh * row_b + 4u * (unsigned)f_c0;
+            d[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, va3[kh][i], sa, 0));
+        } else {
+            const unsigned sb = (unsigned)kh * krow_b + 4u * (unsigned)f_c0 + (unsigned)(i - P) * ustride_b;
+            ub[i - P] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, vb_eff, sb, 0));
+        }
+    };
+    auto fetch_next = [&](int kh) {
+        ++f_kt;
+        if (kh == 2) {
+            f_c0 += BK;
+            if (f_kt >= f_nk) {           // the item's last K step has been fetched: on to the next item of this workgroup
+                f_item += gridDim.x;
+                decode();
+            }
+        }
+    };
+
+    const int st_a = row * LD + 4 * (slot ^ ((row >> 2) & 3));
+    const int st_b = A8_FLOATS + (3 * bhalf) * BN * LD + brow * LD + 4 * (slot ^ ((brow >> 2) & 3));
+    auto stage_one = [&](int p, int img) {
+        if (p >= P) {
+            *reinterpret_cast<float4*>(lds + img + st_b + (p - P) * BN * LD) = ub[p - P];
+            return;
+        }
+        const F4 d0 = to_f4(d[0]), d1 = to_f4(d[1]), d2 = to_f4(d[2]), d3 = to_f4(d[3]), d4 = to_f4(d[4]), d5 = to_f4(d[5]);
+        F4 v;
+        if (p == 0) v = fma4_p4(sub4(d0, d2), sub4(d4, d2));
+        else if (p == 5) v = fma4_m4(sub4(d3, d1), sub4(d5, d3));
+        else if (p <= 2) {
+            const F4 sx = fma4_m4(d2, d4);
+            const F4 tx = fma4_m4(d1, d3);
+            v = p == 1 ? add4(sx, tx) : sub4(sx, tx);
+        } else {
+            const F4 r = sub4(d4, d2), t = sub4(d3, d1);
+            v = p == 3 ? fma4_p2(t, r) : fma4_m2(t, r);
+        }
+        *reinterpret_cast<float4*>(lds + img + st_a + p * BMT8 * LD) = to_float4(v);
+    };
+
+    f32x16 acc[P];
+    const int rsw = 4 * ((lane >> 5) ^ ((lane >> 2) & 3));
+    const int a_off = (wm * 32 + (lane & 31)) * LD + rsw;
+    const int b_off = A8_FLOATS + (wn * 32 + (lane & 31)) * LD + rsw;
+    float4 fa[2][2], fb[2][2];
+    auto frag_one = [&](int g, int set, int i, int img) {
+        const int kb = (g / 3) * 8, xi = 2 * (g % 3) + (i >> 1);
+        if (i & 1) fb[set][i >> 1] = *reinterpret_cast<const float4*>(&lds[img + xi * BN * LD + (b_off ^ kb)]);
+        else       fa[set][i >> 1] = *reinterpret_cast<const float4*>(&lds[img + xi * BMT8 * LD + (a_off ^ kb)]);
+    };
+    auto kstep = [&](int cur, int nxt, int khf) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            const int set = g & 1, x0 = 2 * (g % 3);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = i & 1, e = i >> 1;
+                const float av = e == 0 ? fa[set][j].x : e == 1 ? fa[set][j].y : e == 2 ? fa[set][j].z : fa[set][j].w;
+                const float bv = e == 0 ? fb[set][j].x : e == 1 ? fb[set][j].y : e == 2 ? fb[set][j].z : fb[set][j].w;
+                acc[x0 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[x0 + j], 0, 0, 0);
+                if (i < 4) {
+                    if (g < 5) frag_one(g + 1, set ^ 1, i, cur);
+                    else frag_one(0, 0, i, nxt);
+                } else {
+                    const int s = 4 * (g % 3) + (i - 4);
+                    if (s < 9) {
+                        if (g < 3) stage_one(s, nxt);
+                        else fetch_one(s, khf);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g == 4) {
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        fetch_next(khf);
+    };
+
+    // ---- the compute side starts on the first item: steps 0 and 1 the slow way
+    int c_item = f_item, c_m0 = f_m0, c_n0 = f_n0, c_ns = f_nk - f_kb;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fetch_one(i, 0);
+    fetch_next(0);
+#pragma unroll
+    for (int p = 0; p < 9; ++p) stage_one(p, 0);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fetch_one(i, 1);
+    fetch_next(1);
+    const int ws = __builtin_amdgcn_readfirstlane(wave);
+    float* slab = lds + IMG8_FLOATS + ws * (64 * 36);          // image 1: the image an item's last K step reads
+    for (;;) {
+#ifdef RPG_WINO_TRACE
+        if (g_wino_trace && threadIdx.x == 0) {
+            g_wino_trace[5 * c_item] = __builtin_amdgcn_s_getreg(0xF804);
+            g_wino_trace[5 * c_item + 1] = __builtin_readcyclecounter();
+        }
+#endif
+#pragma unroll
+        for (int xi = 0; xi < P; ++xi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[xi][e] = 0.f;
+        __syncthreads();                 // step 0 of this item is in image 0 (and the previous item's slabs are done with)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) frag_one(0, 0, i, 0);
+#ifdef RPG_WINO_TRACE
+        if (g_wino_trace && threadIdx.x == 0) g_wino_trace[5 * c_item + 2] = __builtin_readcyclecounter();
+#endif
+        for (int s = 0; s < c_ns; s += 6) {
+            kstep(0, IMG8_FLOATS, 2);
+            kstep(IMG8_FLOATS, 0, 0);
+            kstep(0, IMG8_FLOATS, 1);
+            kstep(IMG8_FLOATS, 0, 2);
+            kstep(0, IMG8_FLOATS, 0);
+            kstep(IMG8_FLOATS, 0, 1);
+        }
+        __syncthreads();                 // image 1 becomes the epilogue slabs; image 0 holds the next item's step 0
+#ifdef RPG_WINO_TRACE
+        if (g_wino_trace && threadIdx.x == 0) g_wino_trace[5 * c_item + 3] = __builtin_readcyclecounter();
+#endif
+        // The loads of the next item's K step 1 were skipped by the last K step (kernel row 1 switched off, see decode) so
+        // that the epilogue has their registers; they are issued after its second output transform, when the accumulator
+        // registers are free, and land under the second half's stores, the barrier and the first MFMAs of the next item.
+        auto refetch = [&]() {
+            fix_row1();
+#pragma unroll
+            for (int i = 0; i < 9; ++i) fetch_one(i, 1);
+        };
+        // the epilogue's lane-dependent addressing is item-invariant; left to itself the compiler hoists all of it out of
+        // the item loop and spills it around the K loop (82 VGPRs, reloaded from scratch on the critical path)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        if (c_item < sp.n_split)
+            wino43_epilogue_partial(acc, slab, lane_e, (ws >> 1) * 32, (ws & 1) * 32,
+                                    sp.partial + (size_t)c_item * (BMT8 * 4 * BN), refetch);
+        else
+            wino43_epilogue_lean(acc, slab, lane_e, c_m0 + (ws >> 1) * 32, c_n0 + (ws & 1) * 32, M, Tw, W, Cout, ep, refetch);
+#ifdef RPG_WINO_TRACE
+        if (g_wino_trace && threadIdx.x == 0) g_wino_trace[5 * c_item + 4] = __builtin_readcyclecounter();
+#endif
+        if (f_item >= n_items) break;    // the fetch side is on the item after this one
+        c_item = f_item;
+        c_m0 = f_m0;
+        c_n0 = f_n0;
+        c_ns = f_nk - f_kb;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // The short-K kernel (layers 1-2: Cin <= 128, 12-24 K steps of 16 per tile): 4 waves on 64 tiles x 64 channels, K step 8,
 // TWO LDS images of 24 KB, one barrier per step, and TWO workgroups per CU.
 //
@@ -916,6 +1282,7 @@ __global__ __launch_bounds__(NT) void wino43_weights_kernel(const float* __restr
 
 int g_wino_split = 1;                    // RPG_TUNE_WINO_SPLIT: split-K tail of the 8-wave kernel
 int g_wino = 1;                          // RPG_TUNE_WINOGRAD: 0 off | 1 auto | 2 / 3 / 4: always the 4-wave / 8-wave / short-K kernel
+int g_wino_persist = 1;                  // RPG_TUNE_WINO_PERSIST: the persistent 8-wave kernel when a launch has more tiles than CUs
 int g_wino_short = 0;                    // RPG_TUNE_WINO_SHORT: auto mode uses the short-K kernel up to this many input channels (0 = never)
 
 }  // namespace
@@ -926,6 +1293,7 @@ bool wino_enabled() { return g_wino != 0; }
 void wino_set(int on) { g_wino = on; }
 void wino_split_set(int on) { g_wino_split = on; }
 void wino_short_set(int cin) { g_wino_short = cin; }
+void wino_persist_set(int on) { g_wino_persist = on; }
 
 // Winograd needs (a) 32-bit buffer offsets (checked again by the launcher) and (b) enough work to occupy the chip.  Since
 // the 8-wave kernel cuts a grid that does not fill the CUs along K (split-K tail), that is little: from 16 units of 64
@@ -997,6 +1365,33 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
         long t_main = T;
         Split sp{0, 1, 0, nullptr};
         const long tail = T % S;
+        if (g_wino_persist && cin % 32 == 0 && T > S && h >= 2) {
+            // more tiles than CUs: the persistent kernel, S workgroups walking items b, b + S, ...; the tail tiles are cut
+            // into parts of whole channel-block PAIRS (6 K steps: see the kernel) handed to the first workgroups
+            static bool attr8p[64] = {};
+            if (!attr8p[dev]) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino43_conv8p_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
+                attr8p[dev] = true;
+            }
+            if (g_wino_split && tail > 0) {
+                int parts = (int)(S / tail);
+                if (parts > kpr / 2) parts = kpr / 2;
+                if (parts >= 2) {
+                    sp.partial = stream_scratch(s, (size_t)tail * parts * (BMT8 * 4 * BN) * sizeof(float));
+                    if (sp.partial) { sp.parts = parts; t_main = T - tail; sp.tile_base = (int)t_main; sp.n_split = (int)(tail * parts); }
+                }
+            }
+            const long items = sp.n_split + t_main;
+            hipLaunchKernelGGL(wino43_conv8p_kernel, dim3((unsigned)(items < S ? items : S)), dim3(NT8), LDS8_BYTES, s, x, u, h, w,
+                               cin, cout, tw, (int)M, ep, tn, sp, (int)items);
+            if (sp.n_split)
+                hipLaunchKernelGGL(wino43_fixup_kernel, dim3((unsigned)(T - t_main) * 32), dim3(256), 0, s, sp.partial, ep, (int)M,
+                                   tw, w, cout, tn, sp);
+            timing_end(slot, 2.0 * (double)n * h * w * cout * 9.0 * cin, s, executed);
+            RPG_CHECK_LAUNCH("conv3x3_wino43");
+            return RPG_OK;
+        }
         if (g_wino_split && tail > 0) {
             int parts = (int)(S / tail);
             if (parts > kpr) parts = kpr;               // a part is at least one channel block (3 K steps)

@@ -113,15 +113,19 @@ def test_winograd_at_bench_grids(dev, n, h, c):
     assert tiles == {(56, 128): 784, (56, 256): 1568, (28, 128): 392, (28, 256): 784, (14, 128): 224, (14, 256): 448,
                      (7, 128): 112, (7, 256): 224}[(h, n)]
     errs = {}
-    for split in (1, 0):
-        ops.set_tuning(ops.TUNE_WINO_SPLIT, split)
-        try:
-            y = ops.conv3x3_wino43_bn_act_nhwc(xd, u, scale.to(dev), shift.to(dev), rd, relu=True)
-        finally:
-            ops.set_tuning(ops.TUNE_WINO_SPLIT, 1)
-        errs[split] = rel_err(y.cpu().permute(0, 3, 1, 2), ref)
-    _report({"case": f"wino43_stage_{h}x{h}x{c}_n{n}", "workgroups": tiles, "rel_err_split": errs[1], "rel_err_nosplit": errs[0]})
-    assert errs[1] < 2e-5 and errs[0] < 2e-5, errs
+    for persist in (1, 0):               # more tiles than CUs: the persistent kernel (default) / one workgroup per tile
+        for split in (1, 0):
+            ops.set_tuning(ops.TUNE_WINO_SPLIT, split)
+            ops.set_tuning(ops.TUNE_WINO_PERSIST, persist)
+            try:
+                y = ops.conv3x3_wino43_bn_act_nhwc(xd, u, scale.to(dev), shift.to(dev), rd, relu=True)
+            finally:
+                ops.set_tuning(ops.TUNE_WINO_SPLIT, 1)
+                ops.set_tuning(ops.TUNE_WINO_PERSIST, 1)
+            errs[(persist, split)] = rel_err(y.cpu().permute(0, 3, 1, 2), ref)
+    _report({"case": f"wino43_stage_{h}x{h}x{c}_n{n}", "workgroups": tiles, "rel_err_split": errs[(1, 1)],
+             "rel_err_nosplit": errs[(1, 0)], "rel_err_one_workgroup_per_tile": errs[(0, 1)]})
+    assert max(errs.values()) < 2e-5, errs
 
 
 # bf16 bars: stated on what the bf16 kernels control.  A chain of L bf16-input GEMM layers with
@@ -199,17 +203,19 @@ def test_fuzz_winograd_vs_conv2d(dev, block):
         x, wt, sc, sh, r, relu, _, _, ref = _conv_case(rng, case, True)
         nh = lambda t: None if t is None else t.permute(0, 2, 3, 1).contiguous().to(dev)
         u = ops.wino43_transform_weights(nh(wt))
-        for kern in (2, 3, 4):
+        for kern in (2, 3, 4, 5):        # 5 = the 8-wave kernel without its persistent form
             for split in (0, 1):
                 if kern == 4 and split:
                     continue
-                ops.set_tuning(ops.TUNE_WINOGRAD, kern)
+                ops.set_tuning(ops.TUNE_WINOGRAD, min(kern, 3))
                 ops.set_tuning(ops.TUNE_WINO_SPLIT, split)
+                ops.set_tuning(ops.TUNE_WINO_PERSIST, int(kern != 5))
                 try:
                     y = ops.conv3x3_wino43_bn_act_nhwc(nh(x), u, sc.to(dev), sh.to(dev), nh(r), relu=relu)
                 finally:
                     ops.set_tuning(ops.TUNE_WINOGRAD, 1)
                     ops.set_tuning(ops.TUNE_WINO_SPLIT, 1)
+                    ops.set_tuning(ops.TUNE_WINO_PERSIST, 1)
                 e = rel_err(y.cpu().permute(0, 3, 1, 2), ref)
                 if not e < 2e-5:
                     bad.append((case, kern, split, tuple(x.shape), wt.shape[0], e))

@@ -477,6 +477,46 @@ def test_conv3x3_winograd(dev, n, h, w, cin, cout, res, relu, kernel):
     assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,res", [
+    (100, 24, 30, 32, 96, True),           # 300 tiles: no split possible (one channel-block pair), ragged Cout, Tw = 8
+    (37, 33, 41, 64, 132, True),           # ragged everything: Tw = 11 (3-px last tile), Cout tail of 4 channels, M % 128 != 0
+    (60, 28, 28, 128, 128, False),         # 184 m-tiles x 2: tail of 112 tiles -> 2 parts each
+    (33, 56, 56, 64, 64, True),            # 809 tiles: 3 whole rounds + 41 tail tiles x 2 parts
+    (9, 50, 47, 96, 64, True),             # Cin = 96: three channel-block pairs, odd width
+])
+def test_conv3x3_winograd_persistent(dev, n, h, w, cin, cout, res):
+    """The persistent 8-wave kernel (more tiles than CUs, Cin % 32 == 0: loads pipelined across the tiles of a workgroup)
+    against F.conv2d, with and without the split-K tail, and against the one-workgroup-per-tile kernel to 1e-6 (whole
+    tiles run the same K walk in both; only the output transform is associated differently)."""
+    from relpose_gnn_amd import ops
+    x = _rand(n, cin, h, w, seed=11)
+    wt = _rand(cout, cin, 3, 3, seed=12, scale=(2.0 / (cin * 9)) ** 0.5)
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(13)) + 0.5
+    shift = _rand(cout, seed=14, scale=0.1)
+    ref = F.conv2d(x, wt, None, stride=1, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    r = _rand(*ref.shape, seed=15) if res else None
+    ref = F.relu(ref + r) if res else F.relu(ref)
+    u = ops.wino43_transform_weights(wt.permute(0, 2, 3, 1).contiguous().to(dev))
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    rd = None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev)
+    out = {}
+    for persist in (1, 0):
+        for split in (1, 0):
+            ops.set_tuning(ops.TUNE_WINOGRAD, 3)
+            ops.set_tuning(ops.TUNE_WINO_PERSIST, persist)
+            ops.set_tuning(ops.TUNE_WINO_SPLIT, split)
+            try:
+                out[(persist, split)] = ops.conv3x3_wino43_bn_act_nhwc(xd, u, scale.to(dev), shift.to(dev), rd, relu=True).cpu()
+            finally:
+                ops.set_tuning(ops.TUNE_WINOGRAD, 1)
+                ops.set_tuning(ops.TUNE_WINO_PERSIST, 1)
+                ops.set_tuning(ops.TUNE_WINO_SPLIT, 1)
+    for k, y in out.items():
+        e = rel_err(y.permute(0, 3, 1, 2), ref)
+        assert e < 2e-5, (k, e)
+    assert rel_err(out[(1, 0)], out[(0, 0)]) < 1e-6
+
+
 def test_composite_abi_error_codes(dev):
     """rpg_resnet_forward_f32 / rpg_gnn_forward_f32 reject a wrong tensor table or a short workspace with status codes
     (no launch, no exception across the ABI)."""

@@ -38,8 +38,12 @@ LINEAR = [  # name, m, widths, n_out
 ]
 
 
+WARM = 0
+
+
 def timeit(fn, reps):
-    fn()
+    for _ in range(1 + WARM):      # --warm N: N untimed launches first (clock ramp: a cold GPU runs these kernels ~25 % slower)
+        fn()
     torch.cuda.synchronize()
     ts = []
     for _ in range(reps):
@@ -63,7 +67,14 @@ def main():
     ap.add_argument("--sk", type=int, default=1)
     ap.add_argument("--wino", type=int, default=1)
     ap.add_argument("--nimg", type=int, default=256, help="images in the batch (256 = 32 graphs)")
+    ap.add_argument("--warm", type=int, default=0, help="untimed launches before the timed ones")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="rpg_set_tuning(KEY, VALUE)")
     args = ap.parse_args()
+    global WARM
+    WARM = args.warm
+    for kv in args.tune:
+        k, v = kv.split("=")
+        ops.set_tuning(int(k), int(v))
     dev = torch.device("cuda:0")
     ops.set_tuning(ops.TUNE_BK, args.bk)
     ops.set_tuning(ops.TUNE_EPILOGUE, args.epi)

@@ -17,6 +17,7 @@ lib = _lib.lib()
 lib.rpg_wino_trace_set.argtypes = [C.c_void_p]
 ops.set_tuning(ops.TUNE_WINO_SPLIT, 0)
 ops.set_tuning(ops.TUNE_WINOGRAD, 3)
+ops.set_tuning(ops.TUNE_WINO_PERSIST, int(os.environ.get("PERSIST", "1")))
 for (h, c, res) in ((56, 64, True), (28, 128, True), (14, 256, True), (7, 512, True)):
     n = 256
     x = torch.randn(n, h, h, c, device=dev)
@@ -26,7 +27,7 @@ for (h, c, res) in ((56, 64, True), (28, 128, True), (14, 256, True), (7, 512, T
     r = torch.randn(n, h, h, c, device=dev) if res else None
     tiles = (n * h * ((h + 3) // 4) + 127) // 128 * ((c + 63) // 64)
     buf = torch.zeros(5 * tiles, dtype=torch.int64, device=dev)
-    for _ in range(2):
+    for _ in range(150):                 # clock ramp
         ops.conv3x3_wino43_bn_act_nhwc(x, u, sc, sh, r, relu=True)
     torch.cuda.synchronize()
     assert lib.rpg_wino_trace_set(buf.data_ptr()) == 0
@@ -49,3 +50,8 @@ for (h, c, res) in ((56, 64, True), (28, 128, True), (14, 256, True), (7, 512, T
     print(f"   entries: first 256 within {starts[min(255, tiles-1)]} ticks; entry times of workgroups 256, 512, 1024: "
           f"{starts[min(256, tiles-1)]}, {starts[min(512, tiles-1)]}, {starts[min(1024, tiles-1)]}")
     print(f"   mean workgroup life {np.mean(t[:,4]-t[:,1]):.0f} ticks; sum of lives / 256 CUs = {np.sum(t[:,4]-t[:,1])/256:.0f} ticks vs span {span}")
+    if int(os.environ.get("PERSIST", "1")) and tiles > 256:
+        for b in (0, 101):               # the items of one persistent workgroup, relative to its first timestamp
+            its = t[b::256]
+            base = its[0, 1]
+            print(f"   workgroup {b}: " + "  ".join(f"[{r[1]-base} {r[2]-base} {r[3]-base} {r[4]-base}]" for r in its))
