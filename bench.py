@@ -297,9 +297,10 @@ def main():
                 "what": "achieved = EXECUTED matrix-pipe FLOP of the launches (workgroups x K steps x 48 MFMAs x 8 waves x 4096, "
                         "counted by the launcher; equals SQ_INSTS_VALU_MFMA_F32 x 4096 of the PMC profile) / their summed "
                         "HIP-event durations",
-                "kernel": "wino43_conv8_kernel (3x3/stride-1 conv + BN (+residual) + ReLU as 1-D Winograd F(4,3) on "
-                          "v_mfma_f32_32x32x2_f32; 29 of the 36 ResNet34 convolutions); a launch = the kernel (whole tiles "
-                          "and, on layers with a tail, its split-K workgroups in the same grid) plus wino43_fixup_kernel",
+                "kernel": "wino43_conv8p_kernel / wino43_conv8_kernel (3x3/stride-1 conv + BN (+residual) + ReLU as 1-D Winograd "
+                          "F(4,3) on v_mfma_f32_32x32x2_f32; 29 of the 36 ResNet34 convolutions: the persistent form where a "
+                          "launch has more tiles than CUs, else one workgroup per tile); a launch = the kernel (whole tiles "
+                          "and, on layers with a tail, its split-K parts in the same grid) plus wino43_fixup_kernel",
                 "launches": c["launches"], "avg_launch_ms": round(avg_ms, 4),
                 "executed_gflop_per_launch": round(c["executed"] / c["launches"] / 1e9, 3),
                 "algorithmic": {"gflop_per_launch": round(c["work"] / c["launches"] / 1e9, 3), "tflops": round(alg, 2),

@@ -780,14 +780,22 @@ __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restri
 // them; SQ_BUSY_CU_CYCLES showed CUs without any wave 10-11 % of a layer-1/2 launch against 5 % on the one-round layers
 // 3-4).  What stays: the address set-up of the next item (inside the rarely taken branch of fetch_next, ~1.5 k cycles of
 // VALU) and the epilogue (its registers are the reason for wino43_epilogue_lean: the next item's 9 loads in flight and its
-// offsets stay live across it).  Requirements (else the launcher takes the kernel above): Cin % 32 == 0 -- every item is
-// then a multiple of 6 K steps, so LDS image and kernel-row phase are compile-time constants across items.
+// offsets stay live across it).  Requirements (else the launcher takes the kernel above): Cin % 16 == 0 -- every item is
+// then a whole number of channel blocks (3 K steps), so the kernel-row phase is a compile-time constant across items --
+// and H >= 2 (see fix_row1).
 __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restrict__ x, const float* __restrict__ U, int H,
                                                            int W, int Cin, int Cout, int Tw, int M, Epi ep, int tiles_n,
                                                            Split sp, int n_items) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef RPG_ABL_STAGGER                     // diagnostic (tools/probes/wino_ablate.sh): start the workgroups out of phase
+    {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 7) * RPG_ABL_STAGGER;
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     const int K = 3 * Cin;
-    const int kpr = Cin / BK;                          // channel blocks per kernel row (even)
+    const int kpr = Cin / BK;                          // channel blocks per kernel row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int row = tid >> 2, slot = tid & 3;
@@ -812,8 +820,8 @@ __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restr
         if (f_item < sp.n_split) {
             const int tt = f_item / sp.parts, part = f_item - tt * sp.parts;
             tile = sp.tile_base + tt;
-            kb = 6 * (part * (kpr >> 1) / sp.parts);
-            nk = 6 * ((part + 1) * (kpr >> 1) / sp.parts);
+            kb = 3 * (part * kpr / sp.parts);
+            nk = 3 * ((part + 1) * kpr / sp.parts);
         } else {
             const int nwg = n_items - sp.n_split, bid = f_item - sp.n_split;
             const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r8 = nwg & 7;
@@ -886,9 +894,14 @@ __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restr
 
     const int st_a = row * LD + 4 * (slot ^ ((row >> 2) & 3));
     const int st_b = A8_FLOATS + (3 * bhalf) * BN * LD + brow * LD + 4 * (slot ^ ((brow >> 2) & 3));
-    auto stage_one = [&](int p, int img) {
+    // The two LDS images are addressed through registers (roles X / Y, not compile-time offsets): an item of an odd number
+    // of channel blocks (3, 9, ... K steps) ends on image X, and the roles are swapped so that the next item again starts on X.
+    // (offsets in 16-byte units into lds4: keeps the accesses ds_read_b128 / ds_write_b128 now that they are not constants)
+    struct Img { int a[2], b[2], sa, sb; };         // operand reads of A / B at k half 0 / 1, stage writes of A / B
+    float4* lds4 = reinterpret_cast<float4*>(lds);
+    auto stage_one = [&](int p, const Img& I) {
         if (p >= P) {
-            *reinterpret_cast<float4*>(lds + img + st_b + (p - P) * BN * LD) = ub[p - P];
+            lds4[I.sb + (p - P) * (BN * LD / 4)] = ub[p - P];
             return;
         }
         const F4 d0 = to_f4(d[0]), d1 = to_f4(d[1]), d2 = to_f4(d[2]), d3 = to_f4(d[3]), d4 = to_f4(d[4]), d5 = to_f4(d[5]);
@@ -903,7 +916,7 @@ __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restr
             const F4 r = sub4(d4, d2), t = sub4(d3, d1);
             v = p == 3 ? fma4_p2(t, r) : fma4_m2(t, r);
         }
-        *reinterpret_cast<float4*>(lds + img + st_a + p * BMT8 * LD) = to_float4(v);
+        lds4[I.sa + p * (BMT8 * LD / 4)] = to_float4(v);
     };
 
     f32x16 acc[P];
@@ -911,12 +924,16 @@ __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restr
     const int a_off = (wm * 32 + (lane & 31)) * LD + rsw;
     const int b_off = A8_FLOATS + (wn * 32 + (lane & 31)) * LD + rsw;
     float4 fa[2][2], fb[2][2];
-    auto frag_one = [&](int g, int set, int i, int img) {
-        const int kb = (g / 3) * 8, xi = 2 * (g % 3) + (i >> 1);
-        if (i & 1) fb[set][i >> 1] = *reinterpret_cast<const float4*>(&lds[img + xi * BN * LD + (b_off ^ kb)]);
-        else       fa[set][i >> 1] = *reinterpret_cast<const float4*>(&lds[img + xi * BMT8 * LD + (a_off ^ kb)]);
+    constexpr int IMG4 = IMG8_FLOATS / 4;
+    Img X{{a_off >> 2, (a_off ^ 8) >> 2}, {b_off >> 2, (b_off ^ 8) >> 2}, st_a >> 2, st_b >> 2};
+    Img Y{{X.a[0] + IMG4, X.a[1] + IMG4}, {X.b[0] + IMG4, X.b[1] + IMG4}, X.sa + IMG4, X.sb + IMG4};
+    int ybase = IMG8_FLOATS;               // float offset of image Y (wave-uniform)
+    auto frag_one = [&](int g, int set, int i, const Img& I) {
+        const int xi = 2 * (g % 3) + (i >> 1);
+        if (i & 1) fb[set][i >> 1] = lds4[I.b[g / 3] + xi * (BN * LD / 4)];
+        else       fa[set][i >> 1] = lds4[I.a[g / 3] + xi * (BMT8 * LD / 4)];
     };
-    auto kstep = [&](int cur, int nxt, int khf) {
+    auto kstep = [&](const Img& cur, const Img& nxt, int khf) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
@@ -953,12 +970,31 @@ __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restr
     for (int i = 0; i < 9; ++i) fetch_one(i, 0);
     fetch_next(0);
 #pragma unroll
-    for (int p = 0; p < 9; ++p) stage_one(p, 0);
+    for (int p = 0; p < 9; ++p) stage_one(p, X);
 #pragma unroll
     for (int i = 0; i < 9; ++i) fetch_one(i, 1);
     fetch_next(1);
     const int ws = __builtin_amdgcn_readfirstlane(wave);
-    float* slab = lds + IMG8_FLOATS + ws * (64 * 36);          // image 1: the image an item's last K step reads
+    // ---- residual prefetch into L2.  The epilogue reads 128 KB of residual per tile; issued there, those reads are not
+    // overlapped with anything (measured: a residual costs 30 us per layer-1 launch = its 205 MB at HBM speed).  So at the
+    // start of a tile's last six K steps every lane requests one dword of two of the 128 pixel rows (128 bytes = one cache
+    // line each) of its wave's residual tile; the values are never looked at (pf_val), the lines are in L2 / MALL when the epilogue
+    // wants them.  The two loads are issued on every pass of the K loop body (out-of-range offsets unless it is the last
+    // pass), so the wait counts of the body do not depend on a branch.
+    unsigned pf_off[2] = {OOB, OOB};
+    unsigned pf_val[2] = {0u, 0u};         // "used" after the epilogue, so that the loads exist and are waited for only there
+    auto pf_setup = [&]() {               // offsets of this lane's two pixel rows for the tile (c_m0, c_n0), from its first row
+        int lane_p = lane;
+        asm volatile("" : "+v"(lane_p));
+        const int mw0 = c_m0 + (ws >> 1) * 32, nw0 = c_n0 + (ws & 1) * 32;
+        const int t_first = mw0 / Tw;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int px = lane_p + 64 * k, tile = mw0 + (px >> 2);
+            const int t = tile / Tw, wo = 4 * (tile - t * Tw) + (px & 3);
+            pf_off[k] = tile < M && wo < W && nw0 < Cout ? 4u * (unsigned)(((t - t_first) * W + wo) * Cout + nw0) : OOB;
+        }
+    };
     for (;;) {
 #ifdef RPG_WINO_TRACE
         if (g_wino_trace && threadIdx.x == 0) {
@@ -970,21 +1006,44 @@ __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restr
         for (int xi = 0; xi < P; ++xi)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[xi][e] = 0.f;
-        __syncthreads();                 // step 0 of this item is in image 0 (and the previous item's slabs are done with)
+        __syncthreads();                 // step 0 of this item is in image X (and the previous item's slabs are done with)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) frag_one(0, 0, i, 0);
+        for (int i = 0; i < 4; ++i) frag_one(0, 0, i, X);
 #ifdef RPG_WINO_TRACE
         if (g_wino_trace && threadIdx.x == 0) g_wino_trace[5 * c_item + 2] = __builtin_readcyclecounter();
 #endif
-        for (int s = 0; s < c_ns; s += 6) {
-            kstep(0, IMG8_FLOATS, 2);
-            kstep(IMG8_FLOATS, 0, 0);
-            kstep(0, IMG8_FLOATS, 1);
-            kstep(IMG8_FLOATS, 0, 2);
-            kstep(0, IMG8_FLOATS, 0);
-            kstep(IMG8_FLOATS, 0, 1);
+        int s = 0;
+        const bool pf_item = ep.residual != nullptr && c_item >= sp.n_split;
+        const float* pf_base = pf_item ? ep.residual + (size_t)((c_m0 + (ws >> 1) * 32) / Tw) * W * Cout : x;
+        for (; s + 6 <= c_ns; s += 6) {
+            {
+                const bool now = pf_item && s + 12 > c_ns;       // the last pass of the body
+                if (now) pf_setup();
+                const __amdgpu_buffer_rsrc_t rp =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pf_base), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    pf_val[k] = __builtin_amdgcn_raw_buffer_load_b32(rp, now ? pf_off[k] : OOB, 0, 0);
+                }
+            }
+            kstep(X, Y, 2);
+            kstep(Y, X, 0);
+            kstep(X, Y, 1);
+            kstep(Y, X, 2);
+            kstep(X, Y, 0);
+            kstep(Y, X, 1);
         }
-        __syncthreads();                 // image 1 becomes the epilogue slabs; image 0 holds the next item's step 0
+        if (s < c_ns) {                  // an odd number of channel blocks: three more steps, ending on X -> swap the roles
+            kstep(X, Y, 2);
+            kstep(Y, X, 0);
+            kstep(X, Y, 1);
+            const Img t = X;
+            X = Y;
+            Y = t;
+            ybase = IMG8_FLOATS - ybase;
+        }
+        __syncthreads();                 // image Y (read by the last step) becomes the epilogue slabs; X holds the next item's step 0
+        float* slab = lds + ybase + ws * (64 * 36);
 #ifdef RPG_WINO_TRACE
         if (g_wino_trace && threadIdx.x == 0) g_wino_trace[5 * c_item + 3] = __builtin_readcyclecounter();
 #endif
@@ -1008,6 +1067,7 @@ __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restr
 #ifdef RPG_WINO_TRACE
         if (g_wino_trace && threadIdx.x == 0) g_wino_trace[5 * c_item + 4] = __builtin_readcyclecounter();
 #endif
+        asm volatile("" ::"v"(pf_val[0]), "v"(pf_val[1]));
         if (f_item >= n_items) break;    // the fetch side is on the item after this one
         c_item = f_item;
         c_m0 = f_m0;
@@ -1365,9 +1425,9 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
         long t_main = T;
         Split sp{0, 1, 0, nullptr};
         const long tail = T % S;
-        if (g_wino_persist && cin % 32 == 0 && T > S && h >= 2) {
+        if (g_wino_persist && cin % BK == 0 && T > S && h >= 2) {
             // more tiles than CUs: the persistent kernel, S workgroups walking items b, b + S, ...; the tail tiles are cut
-            // into parts of whole channel-block PAIRS (6 K steps: see the kernel) handed to the first workgroups
+            // into parts of whole channel blocks (3 K steps) handed to the first workgroups
             static bool attr8p[64] = {};
             if (!attr8p[dev]) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino43_conv8p_kernel),
@@ -1376,7 +1436,7 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
             }
             if (g_wino_split && tail > 0) {
                 int parts = (int)(S / tail);
-                if (parts > kpr / 2) parts = kpr / 2;
+                if (parts > kpr) parts = kpr;
                 if (parts >= 2) {
                     sp.partial = stream_scratch(s, (size_t)tail * parts * (BMT8 * 4 * BN) * sizeof(float));
                     if (sp.partial) { sp.parts = parts; t_main = T - tail; sp.tile_base = (int)t_main; sp.n_split = (int)(tail * parts); }

@@ -482,10 +482,13 @@ def test_conv3x3_winograd(dev, n, h, w, cin, cout, res, relu, kernel):
     (37, 33, 41, 64, 132, True),           # ragged everything: Tw = 11 (3-px last tile), Cout tail of 4 channels, M % 128 != 0
     (60, 28, 28, 128, 128, False),         # 184 m-tiles x 2: tail of 112 tiles -> 2 parts each
     (33, 56, 56, 64, 64, True),            # 809 tiles: 3 whole rounds + 41 tail tiles x 2 parts
-    (9, 50, 47, 96, 64, True),             # Cin = 96: three channel-block pairs, odd width
+    (9, 50, 47, 96, 64, True),             # Cin = 96: six channel blocks, odd width
+    (140, 32, 32, 48, 64, True),           # Cin = 48: THREE channel blocks = 9 K steps per tile: the LDS image roles swap after
+                                           # every tile; 280 tiles, tail of 24 -> 3 parts of one channel block each
+    (70, 32, 32, 16, 128, False),          # Cin = 16: one channel block (3 K steps) per tile, no split possible
 ])
 def test_conv3x3_winograd_persistent(dev, n, h, w, cin, cout, res):
-    """The persistent 8-wave kernel (more tiles than CUs, Cin % 32 == 0: loads pipelined across the tiles of a workgroup)
+    """The persistent 8-wave kernel (more tiles than CUs, Cin % 16 == 0: loads pipelined across the tiles of a workgroup)
     against F.conv2d, with and without the split-K tail, and against the one-workgroup-per-tile kernel to 1e-6 (whole
     tiles run the same K walk in both; only the output transform is associated differently)."""
     from relpose_gnn_amd import ops

@@ -17,7 +17,7 @@ timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o p -- python3 $P > "$OUT/pmc_write.log" 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_F32 --output-format csv -d "$OUT/pmc_mfma" -o p -- python3 $P > "$OUT/pmc_mfma.log" 2>&1
 cd "$R"
-python3 tools/pmc_traffic.py "$OUT" "wino43_conv8_kernel" "$OUT/pmc_wino43.json" 32 > "$OUT/pmc_wino43.txt" 2>&1
+python3 tools/pmc_traffic.py "$OUT" "wino43_conv8" "$OUT/pmc_wino43.json" 32 > "$OUT/pmc_wino43.txt" 2>&1
 python3 tools/pmc_summary.py "$OUT" wino43 > "$OUT/pmc_wino43_summary.txt" 2>&1
 python3 tools/pmc_summary.py "$OUT" stem_pool > "$OUT/pmc_stem_summary.txt" 2>&1
 for t in trace_default trace_1stream; do
