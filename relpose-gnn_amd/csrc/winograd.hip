@@ -904,6 +904,10 @@ __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restr
             lds4[I.sb + (p - P) * (BN * LD / 4)] = ub[p - P];
             return;
         }
+#ifdef RPG_ABL_NOXF                        // ablation: no input transform (wrong results, timing only)
+        lds4[I.sa + p * (BMT8 * LD / 4)] = d[p];
+        return;
+#endif
         const F4 d0 = to_f4(d[0]), d1 = to_f4(d[1]), d2 = to_f4(d[2]), d3 = to_f4(d[3]), d4 = to_f4(d[4]), d5 = to_f4(d[5]);
         F4 v;
         if (p == 0) v = fma4_p4(sub4(d0, d2), sub4(d4, d2));
@@ -956,10 +960,12 @@ __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restr
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifndef RPG_ABL_NOBAR                      // ablation: no barrier (wrong results, timing only)
             if (g == 4) {
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
             }
+#endif
         }
         fetch_next(khf);
     };
