@@ -1368,7 +1368,7 @@ bool wino_enabled() { return g_wino != 0; }
 void wino_set(int on) { g_wino = on; }
 void wino_split_set(int on) { g_wino_split = on; }
 void wino_short_set(int cin) { g_wino_short = cin; }
-void wino_persist_set(int on) { g_wino_persist = on; }
+void wino_persist_set(int on) { g_wino_persist = on; }      // 2: also for launches of at most one tile per CU
 
 // Winograd needs (a) 32-bit buffer offsets (checked again by the launcher) and (b) enough work to occupy the chip.  Since
 // the 8-wave kernel cuts a grid that does not fill the CUs along K (split-K tail), that is little: from 16 units of 64
@@ -1440,7 +1440,7 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
         long t_main = T;
         Split sp{0, 1, 0, nullptr};
         const long tail = T % S;
-        if (g_wino_persist && cin % BK == 0 && T > S && h >= 2) {
+        if (g_wino_persist && cin % BK == 0 && (T > S || g_wino_persist == 2) && h >= 2) {
             // more tiles than CUs: the persistent kernel, S workgroups walking items b, b + S, ...; the tail tiles are cut
             // into parts of whole channel blocks (3 K steps) handed to the first workgroups
             static bool attr8p[64] = {};
