@@ -274,7 +274,8 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
 #define RPG_TUNE_WINO_SHORT 12    /* auto mode: convolutions with at most this many input channels on chip-filling grids take the
                                      short-K kernel (two 4-wave workgroups per CU, K step 8); default 0 = never (measured: no gain) */
 #define RPG_TUNE_WINO_PERSIST 14  /* 1: launches with more 8-wave tiles than CUs run the persistent kernel (one workgroup per CU walks its
-                                     tiles, loads pipelined across tiles; needs Cin % 16 == 0) (default) | 0: one workgroup per tile */
+                                     tiles, loads pipelined across tiles; needs Cin % 16 == 0) (default) | 2: also launches of at most one
+                                     tile per CU (measured equal) | 0: one workgroup per tile */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -113,7 +113,7 @@ def test_winograd_at_bench_grids(dev, n, h, c):
     assert tiles == {(56, 128): 784, (56, 256): 1568, (28, 128): 392, (28, 256): 784, (14, 128): 224, (14, 256): 448,
                      (7, 128): 112, (7, 256): 224}[(h, n)]
     errs = {}
-    for persist in (1, 0):               # more tiles than CUs: the persistent kernel (default) / one workgroup per tile
+    for persist in (2, 1, 0):            # the persistent kernel always / where there are more tiles than CUs (default) / never
         for split in (1, 0):
             ops.set_tuning(ops.TUNE_WINO_SPLIT, split)
             ops.set_tuning(ops.TUNE_WINO_PERSIST, persist)
@@ -124,7 +124,8 @@ def test_winograd_at_bench_grids(dev, n, h, c):
                 ops.set_tuning(ops.TUNE_WINO_PERSIST, 1)
             errs[(persist, split)] = rel_err(y.cpu().permute(0, 3, 1, 2), ref)
     _report({"case": f"wino43_stage_{h}x{h}x{c}_n{n}", "workgroups": tiles, "rel_err_split": errs[(1, 1)],
-             "rel_err_nosplit": errs[(1, 0)], "rel_err_one_workgroup_per_tile": errs[(0, 1)]})
+             "rel_err_nosplit": errs[(1, 0)], "rel_err_one_workgroup_per_tile": errs[(0, 1)],
+             "rel_err_persistent_always": errs[(2, 1)]})
     assert max(errs.values()) < 2e-5, errs
 
 
