@@ -981,29 +981,6 @@ __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restr
     for (int i = 0; i < 9; ++i) fetch_one(i, 1);
     fetch_next(1);
     const int ws = __builtin_amdgcn_readfirstlane(wave);
-    // ---- residual prefetch into L2.  The epilogue reads 128 KB of residual per tile; issued there, those reads are not
-    // overlapped with anything (measured: a residual costs 30 us per layer-1 launch = its 205 MB at HBM speed).  So at the
-    // start of a tile's last six K steps every lane requests one dword of two of the 128 pixel rows (128 bytes = one cache
-    // line each) of its wave's residual tile; the values are never looked at (pf_val), the lines are in L2 / MALL when the epilogue
-    // wants them.  The two loads are issued on every pass of the K loop body (out-of-range offsets unless it is the last
-    // pass), so the wait counts of the body do not depend on a branch.
-    // MEASURED (round 2): -1..3 % on the residual convolutions of layers 1-2 (l2: 264 -> 260 us), nothing on the step, and
-    // +25 % L2 fetch traffic (the lines do not survive in the 4-MB L2 next to the K loop's input stream and are fetched
-    // again): compiled out unless RPG_WINO_L2_PREFETCH is defined.
-    unsigned pf_off[2] = {OOB, OOB};
-    unsigned pf_val[2] = {0u, 0u};         // "used" after the epilogue, so that the loads exist and are waited for only there
-    auto pf_setup = [&]() {               // offsets of this lane's two pixel rows for the tile (c_m0, c_n0), from its first row
-        int lane_p = lane;
-        asm volatile("" : "+v"(lane_p));
-        const int mw0 = c_m0 + (ws >> 1) * 32, nw0 = c_n0 + (ws & 1) * 32;
-        const int t_first = mw0 / Tw;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int px = lane_p + 64 * k, tile = mw0 + (px >> 2);
-            const int t = tile / Tw, wo = 4 * (tile - t * Tw) + (px & 3);
-            pf_off[k] = tile < M && wo < W && nw0 < Cout ? 4u * (unsigned)(((t - t_first) * W + wo) * Cout + nw0) : OOB;
-        }
-    };
     for (;;) {
 #ifdef RPG_WINO_TRACE
         if (g_wino_trace && threadIdx.x == 0) {
@@ -1022,23 +999,7 @@ __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restr
         if (g_wino_trace && threadIdx.x == 0) g_wino_trace[5 * c_item + 2] = __builtin_readcyclecounter();
 #endif
         int s = 0;
-#ifdef RPG_WINO_L2_PREFETCH
-        const bool pf_item = ep.residual != nullptr && c_item >= sp.n_split;
-        const float* pf_base = pf_item ? ep.residual + (size_t)((c_m0 + (ws >> 1) * 32) / Tw) * W * Cout : x;
-#endif
         for (; s + 6 <= c_ns; s += 6) {
-#ifdef RPG_WINO_L2_PREFETCH
-            {
-                const bool now = pf_item && s + 12 > c_ns;       // the last pass of the body
-                if (now) pf_setup();
-                const __amdgpu_buffer_rsrc_t rp =
-                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pf_base), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    pf_val[k] = __builtin_amdgcn_raw_buffer_load_b32(rp, now ? pf_off[k] : OOB, 0, 0);
-                }
-            }
-#endif
             kstep(X, Y, 2);
             kstep(Y, X, 0);
             kstep(X, Y, 1);
@@ -1079,9 +1040,6 @@ __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restr
             wino43_epilogue_lean(acc, slab, lane_e, c_m0 + (ws >> 1) * 32, c_n0 + (ws & 1) * 32, M, Tw, W, Cout, ep, refetch);
 #ifdef RPG_WINO_TRACE
         if (g_wino_trace && threadIdx.x == 0) g_wino_trace[5 * c_item + 4] = __builtin_readcyclecounter();
-#endif
-#ifdef RPG_WINO_L2_PREFETCH
-        asm volatile("" ::"v"(pf_val[0]), "v"(pf_val[1]));
 #endif
         if (f_item >= n_items) break;    // the fetch side is on the item after this one
         c_item = f_item;
