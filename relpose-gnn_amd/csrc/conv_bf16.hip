@@ -62,8 +62,23 @@ __device__ __forceinline__ void bf16_tile_epilogue(f32x16 (&acc)[FM][FN], unsign
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n_ok && ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + nb);
     if (n_ok && ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + nb);
+    // The bf16 residual rows of a 32-row fragment are requested as one batch, one fragment ahead (unconditional loads on
+    // clamped addresses): read one at a time inside the row loop below, each was a fully exposed round trip (measured at
+    // 512 images: a residual cost +122 us on a layer-1 convolution, +58 us on layer 2 -- five times its HBM time).
+    bf16x4 rs_cur[NIT], rs_nxt[NIT];
+    auto load_res = [&](int i, bf16x4 (&dst)[NIT]) {
+        if (!ep.residual) return;
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int m = m0 + (wm * FM + i) * 32 + r_in + RPI * t;
+            const size_t o = n_ok && m < M ? (size_t)m * ep.ldc + nb : 0;
+            dst[t] = *reinterpret_cast<const bf16x4*>(ep.residual + o);
+        }
+    };
+    load_res(0, rs_cur);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
+        if (i + 1 < FM) load_res(i + 1, rs_nxt);
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
@@ -81,7 +96,7 @@ __device__ __forceinline__ void bf16_tile_epilogue(f32x16 (&acc)[FM][FN], unsign
                 float4 y;
                 y.x = v.x * sc.x + sh.x; y.y = v.y * sc.y + sh.y; y.z = v.z * sc.z + sh.z; y.w = v.w * sc.w + sh.w;
                 if (ep.residual) {
-                    const bf16x4 rs = *reinterpret_cast<const bf16x4*>(ep.residual + o);
+                    const bf16x4 rs = rs_cur[t];
                     y.x += (float)rs[0]; y.y += (float)rs[1]; y.z += (float)rs[2]; y.w += (float)rs[3];
                 }
                 if (ep.res_f32) {
@@ -103,6 +118,8 @@ __device__ __forceinline__ void bf16_tile_epilogue(f32x16 (&acc)[FM][FN], unsign
             }
         }
         __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) rs_cur[t] = rs_nxt[t];
     }
 }
 
@@ -306,12 +323,16 @@ __global__ __launch_bounds__(NT) void conv_bf16_fast_kernel(ConvArgsB a, const _
         for (int j = 0; j < RW; ++j) weff[j] = live ? woff[j] : OOB;
     };
     refresh();
-    uint4 rr[NJ];                                         // staging registers: A rows, then W rows
-    auto load_job = [&](int qj) {
+    // Staging registers (A rows, then W rows), TWO sets: K step t stages step t+1 from set (t+1) & 1 and then loads step t+3
+    // into the same set, so a load has two and a half steps to land.  (With one set -- loaded half a step before it is
+    // staged -- a step of 16 MFMAs x 32 cycles hid nothing of a 2-5 k-cycle round trip: the 128 x 128 kernel ran at 3.1 k
+    // cycles per step and pair of workgroups, 1 k of them MFMA.)
+    uint4 rr[2][NJ];
+    auto load_job = [&](int qj, int set) {
         if (qj < RA)
-            rr[qj] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsa, voff[qj], 2u * (unsigned)c0, 0));
+            rr[set][qj] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsa, voff[qj], 2u * (unsigned)c0, 0));
         else
-            rr[qj] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsw, weff[qj - RA], 2u * (unsigned)k0, 0));
+            rr[set][qj] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsw, weff[qj - RA], 2u * (unsigned)k0, 0));
     };
     auto next_k = [&]() {
         k0 += BK;
@@ -322,9 +343,9 @@ __global__ __launch_bounds__(NT) void conv_bf16_fast_kernel(ConvArgsB a, const _
         }
     };
     const int st_off = srow * LD + 8 * (slot ^ ((srow >> 1) & 7));      // ROWS_PER_PASS is a multiple of 16: same swizzle per pass
-    auto write_job = [&](int qj, int im) {
+    auto write_job = [&](int qj, int im, int set) {
         const int rrow = qj < RA ? ROWS_PER_PASS * qj : BM + ROWS_PER_PASS * (qj - RA);
-        *reinterpret_cast<uint4*>(&lds[im + st_off + rrow * LD]) = rr[qj];
+        *reinterpret_cast<uint4*>(&lds[im + st_off + rrow * LD]) = rr[set][qj];
     };
     // operand fragment of lane (row = lane & 31, k half = lane >> 5) for the 16-wide k group g: logical chunk 2g + half
     const int lrow = lane & 31, sw = (lrow >> 1) & 7, half = lane >> 5;
@@ -344,7 +365,7 @@ __global__ __launch_bounds__(NT) void conv_bf16_fast_kernel(ConvArgsB a, const _
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // side jobs of MFMA group g: the NR operand reads of the next group, then (g < KB-2 .. ) stage writes / loads
-    auto kstep = [&](int cur, int nxt) {
+    auto kstep = [&](int cur, int nxt, int set_n) {       // set_n: the register set of the step staged into nxt
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < KB; ++g) {
@@ -365,8 +386,8 @@ __global__ __launch_bounds__(NT) void conv_bf16_fast_kernel(ConvArgsB a, const _
                     } else if (job < JOBS) {
                         const int w = (g % (KB / 2)) * WPG + (job - NR);
                         if (w < NJ) {
-                            if (g < KB / 2) write_job(w, nxt);
-                            else load_job(w);
+                            if (g < KB / 2) write_job(w, nxt, set_n);
+                            else load_job(w, set_n);
                         }
                     }
                 }
@@ -381,12 +402,15 @@ __global__ __launch_bounds__(NT) void conv_bf16_fast_kernel(ConvArgsB a, const _
     };
 
 #pragma unroll
-    for (int qj = 0; qj < NJ; ++qj) load_job(qj);
+    for (int qj = 0; qj < NJ; ++qj) load_job(qj, 0);      // step 0
     next_k();
 #pragma unroll
-    for (int qj = 0; qj < NJ; ++qj) write_job(qj, 0);
+    for (int qj = 0; qj < NJ; ++qj) load_job(qj, 1);      // step 1
+    next_k();
 #pragma unroll
-    for (int qj = 0; qj < NJ; ++qj) load_job(qj);
+    for (int qj = 0; qj < NJ; ++qj) write_job(qj, 0, 0);
+#pragma unroll
+    for (int qj = 0; qj < NJ; ++qj) load_job(qj, 0);      // step 2
     next_k();
     __syncthreads();
 #pragma unroll
@@ -394,14 +418,15 @@ __global__ __launch_bounds__(NT) void conv_bf16_fast_kernel(ConvArgsB a, const _
     const int nk = K / BK;
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
-        kstep(0, STAGE);
-        kstep(STAGE, 0);
+        kstep(0, STAGE, 1);
+        kstep(STAGE, 0, 0);
     }
-    if (kt < nk) kstep(0, STAGE);
+    if (kt < nk) kstep(0, STAGE, 1);
     __syncthreads();
     bf16_tile_epilogue<FM, FN, 2 * STAGE * 2>(acc, lds_raw, ep, m0, n0, M, N, wm, wn, lane, wave);
 }
 
+int g_bf16_tile = -1;    // RPG_TUNE_BF16_TILE: -1 auto | 0: 64x64 | 1: 128x128 | 2: 256x64 (interleaved kernel only)
 int g_bf16_fast = 1;     // RPG_TUNE_BF16_FAST: the interleaved buffer-load kernel where eligible
 int g_bf16_bk = 32;      // measured on MI355X at 64 graphs: K step 32 -> 9.97 ms/step, 64 -> 12.5 (the 72-KB LDS image halves occupancy)
 
@@ -516,6 +541,7 @@ namespace rpg {
 
 void bf16_set_bk(int bk) { g_bf16_bk = bk; }
 void bf16_set_fast(int on) { g_bf16_fast = on; }
+void bf16_set_tile(int t) { g_bf16_tile = t; }
 
 // fp32 [rows][ld_src] (first `cols` columns) -> bf16 dst[rows][ld_dst] at column offset col_off (cols % 8 == 0)
 __global__ __launch_bounds__(NT) void f32_to_bf16_kernel(const float* __restrict__ src, int ld_src, __bf16* __restrict__ dst,
@@ -589,7 +615,11 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
     // first image of a tile (whose <= 256 rows span at most 256 / (ho*wo) + 2 images)
     const long span = 256 / ((long)ho * wo) + 2;
     const bool fast = g_bf16_fast && cin % 64 == 0 && span * h * wd * cin * 2 < (1L << 31) && (long)cout * K * 2 < (1L << 31);
-    if (fast) {
+    if (fast && g_bf16_tile >= 0) {       // RPG_TUNE_BF16_TILE: forced tile of the interleaved kernel (experiments)
+        if (g_bf16_tile == 0) launch_fast<64, 64, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);
+        else if (g_bf16_tile == 1) launch_fast<128, 128, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);
+        else launch_fast<256, 64, 4, 1>(a, wp, (int)M, cout, (int)K, ep, s);
+    } else if (fast) {
         if (cout <= 64 && M >= 65536) launch_fast<256, 64, 4, 1>(a, wp, (int)M, cout, (int)K, ep, s);
         else if (cout <= 64 || (long)((M + 127) / 128) * ((cout + 127) / 128) < 256) launch_fast<64, 64, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);
         else launch_fast<128, 128, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);

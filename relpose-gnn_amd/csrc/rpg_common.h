@@ -77,6 +77,7 @@ void wino_split_set(int on);
 void wino_short_set(int cin);
 void wino_persist_set(int on);
 void bf16_set_fast(int on);
+void bf16_set_tile(int t);
 int launch_f32_to_bf16(const float* src, int ld_src, void* dst, int ld_dst, int col_off, long rows, int cols, hipStream_t s);
 int launch_linear_bf16(const void* a, const void* w, const float* bias, const float* res, const int64_t* res_idx,
                        const float* res2, const int64_t* res2_idx, int ldr, float* out, int m, int k, int n_out, int relu,

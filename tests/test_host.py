@@ -47,7 +47,7 @@ def test_tuning_and_timer_constants_match_the_header():
     assert lib.rpg_set_tuning(defs["RPG_TUNE_BK"], 24) == _lib.RPG_ERR_BAD_ARG
     assert lib.rpg_set_tuning(defs["RPG_TUNE_WINOGRAD"], 7) == _lib.RPG_ERR_BAD_ARG
     for name, key in tune.items():                                    # defaults are accepted and restore the defaults
-        default = {"TILE": -1, "BK": 0, "BF16_BK": 32, "WINO_SHORT": 0}.get(name, 1)
+        default = {"TILE": -1, "BK": 0, "BF16_BK": 32, "WINO_SHORT": 0, "BF16_TILE": -1}.get(name, 1)
         assert lib.rpg_set_tuning(key, default) == 0, name
 
 

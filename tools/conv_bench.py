@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--wino", type=int, default=1)
     ap.add_argument("--nimg", type=int, default=256, help="images in the batch (256 = 32 graphs)")
     ap.add_argument("--warm", type=int, default=0, help="untimed launches before the timed ones")
+    ap.add_argument("--bf16", action="store_true", help="the bf16 convolution kernels (bf16 activations / weights) instead of fp32")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="rpg_set_tuning(KEY, VALUE)")
     args = ap.parse_args()
     global WARM
@@ -91,7 +92,13 @@ def main():
         sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.1
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
         r = torch.randn(n, ho, wo, cout, device=dev) if res else None
-        if args.wino and k == 3 and s == 1:
+        if args.bf16:
+            if name == "stem":
+                continue
+            xb, wb = x.bfloat16(), wt.bfloat16()
+            rb = None if r is None else r.bfloat16()
+            med, best = timeit(lambda: ops.conv2d_bn_act_nhwc_bf16(xb, wb, sc, sh, rb, stride=s, pad=p, relu=True), args.reps)
+        elif args.wino and k == 3 and s == 1:
             u = ops.wino43_transform_weights(wt)
             name = name + "w"
             med, best = timeit(lambda: ops.conv3x3_wino43_bn_act_nhwc(x, u, sc, sh, r, relu=True), args.reps)
