@@ -276,7 +276,7 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
 #define RPG_TUNE_WINO_PERSIST 14  /* 1: launches with more 8-wave tiles than CUs run the persistent kernel (one workgroup per CU walks its
                                      tiles, loads pipelined across tiles; needs Cin % 16 == 0) (default) | 2: also launches of at most one
                                      tile per CU (measured equal) | 0: one workgroup per tile */
-#define RPG_TUNE_BF16_TILE 15     /* tile of the interleaved bf16 convolution kernel: -1 by shape (default) | 0: 64x64 | 1: 128x128 | 2: 256x64 */
+#define RPG_TUNE_BF16_TILE 15     /* tile of the interleaved bf16 convolution kernel: -1 by shape (default) | 0: 64x64 | 1: 128x128 | 2: 256x64 | 3: 128x64 */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(NT) void conv_bf16_fast_kernel(ConvArgsB a, const _
     bf16_tile_epilogue<FM, FN, 2 * STAGE * 2>(acc, lds_raw, ep, m0, n0, M, N, wm, wn, lane, wave);
 }
 
-int g_bf16_tile = -1;    // RPG_TUNE_BF16_TILE: -1 auto | 0: 64x64 | 1: 128x128 | 2: 256x64 (interleaved kernel only)
+int g_bf16_tile = -1;    // RPG_TUNE_BF16_TILE: -1 auto | 0: 64x64 | 1: 128x128 | 2: 256x64 | 3: 128x64 (interleaved kernel only)
 int g_bf16_fast = 1;     // RPG_TUNE_BF16_FAST: the interleaved buffer-load kernel where eligible
 int g_bf16_bk = 32;      // measured on MI355X at 64 graphs: K step 32 -> 9.97 ms/step, 64 -> 12.5 (the 72-KB LDS image halves occupancy)
 
@@ -618,9 +618,11 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
     if (fast && g_bf16_tile >= 0) {       // RPG_TUNE_BF16_TILE: forced tile of the interleaved kernel (experiments)
         if (g_bf16_tile == 0) launch_fast<64, 64, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);
         else if (g_bf16_tile == 1) launch_fast<128, 128, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);
+        else if (g_bf16_tile == 3) launch_fast<128, 64, 4, 1>(a, wp, (int)M, cout, (int)K, ep, s);
         else launch_fast<256, 64, 4, 1>(a, wp, (int)M, cout, (int)K, ep, s);
     } else if (fast) {
-        if (cout <= 64 && M >= 65536) launch_fast<256, 64, 4, 1>(a, wp, (int)M, cout, (int)K, ep, s);
+        // Cout = 64 on many rows (layer 1): 128 x 64 (three workgroups per CU; 238 vs 251 us with 256 x 64 at 512 images)
+        if (cout <= 64 && M >= 65536) launch_fast<128, 64, 4, 1>(a, wp, (int)M, cout, (int)K, ep, s);
         else if (cout <= 64 || (long)((M + 127) / 128) * ((cout + 127) / 128) < 256) launch_fast<64, 64, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);
         else launch_fast<128, 128, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);
     } else if (cout <= 64 && M >= 65536) {

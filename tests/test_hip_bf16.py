@@ -32,7 +32,7 @@ def _rand(*shape, seed=0, scale=1.0):
     (1, 16, 16, 8, 64, 7, 2, 3, False, True, False),      # stem shape with Cin padded to 8
     (2, 14, 14, 64, 128, 3, 2, 1, True, True, False),     # strided, residual
     (2, 14, 14, 64, 128, 1, 2, 0, False, False, False),   # downsample 1x1
-    (40, 56, 56, 64, 64, 3, 1, 1, True, True, False),     # layer1 shape -> 256x64 tile
+    (40, 56, 56, 64, 64, 3, 1, 1, True, True, False),     # layer1 shape -> 128x64 tile
     (64, 28, 28, 128, 128, 3, 1, 1, True, True, False),   # 128x128 tile
     (37, 1, 1, 512, 2048, 1, 1, 0, False, False, True),   # the fc as a 1x1 conv on a 1x1 image, fp32 output
     (3, 13, 17, 192, 72, 3, 2, 1, True, True, False),     # ragged M and N, 3 K steps per tap (odd step count), padding taps
@@ -61,6 +61,29 @@ def test_conv_bf16(dev, n, h, w, cin, cout, k, stride, pad, res, relu, f32out, f
     assert y.dtype == (torch.float32 if f32out else torch.bfloat16)
     err = rel_err(y.float().cpu().permute(0, 3, 1, 2), ref)
     assert err < (1e-5 if f32out else 1e-2), err
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3], ids=["64x64", "128x128", "256x64", "128x64"])
+def test_conv_bf16_interleaved_tiles(dev, tile):
+    """Every tile of the interleaved bf16 kernel (RPG_TUNE_BF16_TILE) on a shape with a residual, ragged rows (M % 256 != 0),
+    a ragged channel tile (Cout = 72) and an odd number of K steps per workgroup."""
+    from relpose_gnn_amd import ops
+    n, h, w, cin, cout = 5, 23, 19, 64, 72
+    x = _rand(n, cin, h, w, seed=21).bfloat16()
+    wt = _rand(cout, cin, 3, 3, seed=22, scale=(2.0 / (cin * 9)) ** 0.5).bfloat16()
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(23)) + 0.5
+    shift = _rand(cout, seed=24, scale=0.1)
+    r = _rand(n, cout, h, w, seed=25).bfloat16()
+    ref = F.relu(F.conv2d(x.float(), wt.float(), None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + r.float())
+    ops.set_tuning(ops.TUNE_BF16_TILE, tile)
+    try:
+        y = ops.conv2d_bn_act_nhwc_bf16(x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev),
+                                        scale.to(dev), shift.to(dev), r.permute(0, 2, 3, 1).contiguous().to(dev), stride=1, pad=1,
+                                        relu=True)
+    finally:
+        ops.set_tuning(ops.TUNE_BF16_TILE, -1)
+    err = rel_err(y.float().cpu().permute(0, 3, 1, 2), ref)
+    assert err < 1e-2, err
 
 
 def test_bf16_encoder_forward_vs_fp32_oracle(dev):
