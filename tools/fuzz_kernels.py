@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the convolution kernels against each other on random shapes (GPU box, ~30 s):
-  * both Winograd kernels, with and without the split-K tail, vs the direct implicit-GEMM kernel (400 shapes);
+  * the Winograd kernels (4-wave, 8-wave, persistent 8-wave), with and without the split-K tail, vs the direct implicit-GEMM kernel (400 shapes);
   * the buffer-load loaders of the tile engine vs the general loaders over random tile / K-step / stream-K choices
     (300 shapes, strides 1-3, paddings 0-3, 4-channel tap-loader cases included).
 Prints every mismatch and a final count; exit code 1 if any.     python tools/fuzz_kernels.py [--cases-scale 1.0]"""
@@ -23,7 +23,11 @@ def fuzz_winograd(dev, cases):
     bad, rng = 0, random.Random(12345)
     for case in range(cases):
         cin, cout = 4 * rng.randint(1, 48), 4 * rng.randint(1, 80)
+        if case % 2:
+            cin = 16 * rng.randint(1, 12)         # whole channel blocks: eligible for the persistent kernel
         n, h, w = rng.randint(1, 40), rng.randint(1, 40), rng.randint(1, 60)
+        if case % 8 == 7:
+            n = rng.randint(60, 200)              # more 128-tile workgroups than CUs: several items per workgroup
         res, relu = rng.random() < 0.5, rng.random() < 0.5
         g = torch.Generator().manual_seed(case)
         x = torch.randn(n, h, w, cin, generator=g).to(dev)
@@ -32,16 +36,18 @@ def fuzz_winograd(dev, cases):
         r = torch.randn(n, h, w, cout, generator=g).to(dev) if res else None
         ref = ops.conv2d_bn_act_nhwc(x, wt, sc, sh, r, stride=1, pad=1, relu=relu)
         u = ops.wino43_transform_weights(wt)
-        for kern in (2, 3):
+        for kern, persist in ((2, 1), (3, 0), (3, 2)):      # persist 2: the persistent 8-wave kernel wherever Cin % 16 == 0
             for split in (0, 1):
                 ops.set_tuning(ops.TUNE_WINOGRAD, kern)
                 ops.set_tuning(ops.TUNE_WINO_SPLIT, split)
+                ops.set_tuning(ops.TUNE_WINO_PERSIST, persist)
                 e = rel(ops.conv3x3_wino43_bn_act_nhwc(x, u, sc, sh, r, relu=relu), ref)
                 if not e < 3e-5:
                     bad += 1
-                    print("MISMATCH winograd", case, kern, split, (n, h, w, cin, cout, res, relu), e, flush=True)
+                    print("MISMATCH winograd", case, kern, persist, split, (n, h, w, cin, cout, res, relu), e, flush=True)
     ops.set_tuning(ops.TUNE_WINOGRAD, 1)
     ops.set_tuning(ops.TUNE_WINO_SPLIT, 1)
+    ops.set_tuning(ops.TUNE_WINO_PERSIST, 1)
     return bad
 
 
