@@ -12,12 +12,15 @@
 // So one convolution = 6 independent GEMMs  [tiles x 3*Cin] * [3*Cin x Cout]  whose accumulators a lane combines
 // in registers at the end (the output transform is lane-local: the MFMA C layout puts the same (tile, cout) element
 // of all 6 products in the same lane); a wave owns 32 tiles x 32 channels x 6 positions = 6 accumulators of 32x32.
-// Two kernels share the addressing, the LDS layout (64-byte rows of four 16-byte chunks, XOR-swizzled by row) and
+// The kernels share the addressing, the LDS layout (64-byte rows of four 16-byte chunks, XOR-swizzled by row) and
 // the epilogue (output transform, LDS transpose, BatchNorm / residual / ReLU through raw buffer accesses):
-//   * wino43_conv8_kernel (the one that matters): 8 waves on 128 tiles x 64 channels, two LDS images of a 16-wide K
-//     step, one barrier per step, every load / LDS access placed singly behind an MFMA; its first blocks are the split-K
-//     variant for the tiles beyond the last full round of CUs, finished by wino43_fixup_kernel;
-//   * wino43_conv_kernel: 4 waves on 64 tiles x 64 channels, one LDS image, two workgroups per CU: small grids.
+//   * wino43_conv8_kernel: 8 waves on 128 tiles x 64 channels, two LDS images of a 16-wide K step, one barrier per step,
+//     every load / LDS access placed singly behind an MFMA; its first blocks are the split-K variant for the tiles beyond
+//     the last full round of CUs, finished by wino43_fixup_kernel;
+//   * wino43_conv8p_kernel (the one that matters: every launch with more tiles than CUs): the same K step in a persistent
+//     workgroup that walks its tiles with the load pipeline running across them;
+//   * wino43_conv_kernel: 4 waves on 64 tiles x 64 channels, one LDS image, two workgroups per CU: small grids;
+//   * wino43_conv4d_kernel: a measured-and-shelved short-K variant (two 4-wave workgroups per CU).
 // The design rules come from tools/probes/mfma_shadow_probe.hip: VALU time does not hide behind f32 MFMAs on gfx950.
 //
 // Reference op replaced: nn.Conv2d(3x3, stride 1, pad 1) + nn.BatchNorm2d (eval) (+ identity) + ReLU of a torchvision
@@ -773,8 +776,8 @@ __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restri
 // The persistent form of the 8-wave kernel (round 2): one workgroup per CU walks a list of work items -- item =
 // blockIdx.x + i * gridDim.x over [split-K parts | whole tiles], same item -> tile mapping as above -- and the load /
 // stage pipeline runs ACROSS items: during the last two K steps of an item the buffer loads already fetch steps 0 and 1 of
-// the next item, the last step stages the next item's step 0 into LDS image 0, and the epilogue uses image 1 (the one the
-// last step read) for its slabs.  What that removes per tile: the cold prologue (address set-up, one exposed HBM round
+// the next item, the last step stages the next item's step 0 into the other LDS image, and the epilogue uses the image the
+// last step read for its slabs.  What that removes per tile: the cold prologue (address set-up, one exposed HBM round
 // trip, first stage + barrier: 6.5-10.7 k cycles, profiles/r1_wino43_phase_cycles.txt) and the gap between a workgroup's
 // exit and its successor's first instruction on the CU (one 144-KB-LDS workgroup per CU: the dispatcher cannot overlap
 // them; SQ_BUSY_CU_CYCLES showed CUs without any wave 10-11 % of a layer-1/2 launch against 5 % on the one-round layers

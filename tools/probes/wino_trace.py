@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timeline of wino43_conv8_kernel<false> per CU from the RPG_WINO_TRACE build (tools/probes/wino_trace.sh): for every
+"""Timeline of the 8-wave Winograd kernels (PERSIST=1: wino43_conv8p_kernel, per item; PERSIST=0: wino43_conv8_kernel) per CU from the RPG_WINO_TRACE build (tools/probes/wino_trace.sh): for every
 workgroup HW_ID and s_memtime at entry / after the prologue / after the K loop / at exit.  Prints phase medians and, per
 CU, the gaps between one workgroup's exit and the next one's entry (dispatch latency the in-kernel timers cannot see)."""
 import ctypes as C
