@@ -80,7 +80,7 @@ def errors(pred_poses: np.ndarray, targ_poses: np.ndarray) -> EvalResult:
 
 
 @torch.no_grad()
-def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 32, pose_m=(0.0, 0.0, 0.0),
+def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64, pose_m=(0.0, 0.0, 0.0),
                     pose_s=(1.0, 1.0, 1.0), ref_node: int = 0, rank: int = 0, world: int = 1) -> EvalResult:
     """Run ``model`` over a stream of single-graph ``Data`` objects (x, edge_index, y) and post-process like test.py.
     With world > 1 every rank evaluates its contiguous block (shard_range) and the [G,7] rows are all-gathered.

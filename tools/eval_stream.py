@@ -26,7 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--graphs", type=int, default=2000)
     ap.add_argument("--shape", default="256x341")
-    ap.add_argument("--micro-batch", type=int, default=32)
+    ap.add_argument("--micro-batch", type=int, default=64, help="graphs per forward (64: +5 % over 32 at 256x341 with the persistent Winograd kernel)")
     ap.add_argument("--encoder-dtype", choices=("f32", "bf16"), default="f32")
     ap.add_argument("--gnn-dtype", choices=("f32", "bf16"), default="f32")
     ap.add_argument("--knn", type=int, default=-1, help="the reference's --knn (test.py:308 defaults to 4): the model rebuilds "
