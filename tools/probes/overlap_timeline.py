@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """How the two streams of the default bench overlap: from a rocprofv3 --kernel-trace CSV, the share of the timed window with
 0 / 1 / 2+ kernels in flight, and for the one-kernel periods which kernel was running alone (its launches do not fill the
-chip by themselves if it is a small grid).  usage: overlap_timeline.py <dir with *_kernel_trace.csv>"""
+chip by themselves if it is a small grid), plus the periods with fewer than 256 workgroups in flight.  Caveat: kernel tracing
+slows the host's launches (12.6 instead of 10.5 ms per step in one run), so one stream can fall behind the other and kernels
+run alone that overlap in the un-profiled run; two runs of this tool gave 77 % and 43 % "two or more".
+usage: overlap_timeline.py <dir with *_kernel_trace.csv>"""
 import csv
 import glob
 import sys
@@ -25,11 +28,14 @@ ev.sort()
 active, last = {}, t0
 dur = defaultdict(float)
 alone = defaultdict(float)
+small = defaultdict(float)            # periods in which the kernels in flight have < 256 workgroups between them
 for t, d, name, wgs in ev:
     n = len(active)
     dur[min(n, 2)] += t - last
     if n == 1:
         alone[next(iter(active.values()))] += t - last
+    if n >= 1 and sum(v[1] for v in active.values()) < 256:
+        small[" + ".join(sorted(f"{v[0]}[{v[1]}]" for v in active.values()))] += t - last
     last = t
     key = (name, wgs)
     if d > 0:
@@ -43,5 +49,8 @@ for t, d, name, wgs in ev:
 tot = t1 - t0
 print(f"window {tot/1e6:.2f} ms: idle {100*dur[0]/tot:.1f} %, one kernel {100*dur[1]/tot:.1f} %, two or more {100*dur[2]/tot:.1f} %")
 print("alone (share of the window, kernel, workgroups):")
-for (name, wgs), v in sorted(alone.items(), key=lambda kv: -kv[1])[:14]:
+for (name, wgs), v in sorted(alone.items(), key=lambda kv: -kv[1])[:10]:
     print(f"  {100*v/tot:5.1f} %  {name:40s} {wgs}")
+print(f"fewer than 256 workgroups in flight: {100*sum(small.values())/tot:.1f} % of the window:")
+for k, v in sorted(small.items(), key=lambda kv: -kv[1])[:12]:
+    print(f"  {100*v/tot:5.2f} %  {k}")
