@@ -47,8 +47,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--graphs", type=int, default=32, help="graphs per step per GPU (configs[1]: 32)")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=180.0,
+                    help="budget of the whole CPU baseline leg (three thread counts x B = 1/8/32); 0 disables it")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--launcher", action="store_true",
+                    help="start the rank(s) through this script's own torch.distributed.run command line even for --gpus 1: the "
+                         "launcher, RCCL initialisation and the per-step all-gather then run on a one-GPU box too")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU the batch is spread over in the timed region")
     ap.add_argument("--gnn-dtype", choices=("f32", "bf16"), default="f32",
                     help="bf16: the GNN's Linears on the bf16 matrix pipe too (only meaningful with --encoder-dtype bf16)")
@@ -61,53 +65,99 @@ def parse():
     return ap.parse_args()
 
 
-CPU_THREADS_PER_WORKER = 32      # measured optimum of torch-CPU for this model on the EPYC host (tests/probes/cpu_threads_probe.py)
+CPU_THREADS_BEST = 32      # measured optimum of torch-CPU for this model on the 2 x EPYC 9575F host (tests/probes/cpu_threads_probe.py)
+
+
+def physical_cores() -> int:
+    """Physical cores of the host ("state the count from lscpu"); falls back to logical / 2."""
+    try:
+        import subprocess
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        f = {ln.split(":", 1)[0].strip(): ln.split(":", 1)[1].strip() for ln in out.splitlines() if ":" in ln}
+        n = int(f["Core(s) per socket"]) * int(f["Socket(s)"])
+        if n > 0:
+            return n
+    except Exception:
+        pass
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
 
 
 def cpu_worker(budget_s: float, threads: int):
-    """One CPU-baseline worker: oracle forwards (PyTorch CPU fp32) on 4-graph batches for ~budget_s; prints a JSON line."""
+    """One CPU-baseline worker = one thread count: the oracle forward (PyTorch CPU fp32) at B = 1, 8 and 32 graphs per
+    forward, 1 warm-up + the median of 3 timed forwards each; a cell whose projected cost does not fit
+    what is left of ``budget_s`` is recorded as skipped instead of run.  Prints one JSON line."""
     from oracle import posenet_ref as O              # the checker, timed here as the reported CPU baseline
     import relpose_gnn_amd.synth as S
     torch.set_num_threads(threads)
     sd = S.synth_state_dict(S.posenet_r2_param_shapes(), seed=1)
-    g = 4
-    x = S.synth_images(NODES * g, IMG, IMG, seed=77)
-    ei = O.batch_edge_index(NODES, g)
-    O.posenet_forward(sd, x, ei, IMG, 2)             # warm-up
-    t0 = time.perf_counter()
-    iters = 0
-    while True:
-        O.posenet_forward(sd, x, ei, IMG, 2)
-        iters += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or iters >= 200:
-            break
-    print(json.dumps({"graphs": g * iters, "seconds": dt}), flush=True)
+    t_start = time.perf_counter()
+    cells, per_graph = [], None
+    for g in (1, 8, 32):
+        left = budget_s - (time.perf_counter() - t_start)
+        if per_graph is not None and 4 * g * per_graph > left:
+            cells.append({"threads": threads, "graphs_per_forward": g, "skipped": f"projected {4 * g * per_graph:.0f} s > {left:.0f} s left of this thread count's budget"})
+            continue
+        x = S.synth_images(NODES * g, IMG, IMG, seed=77)
+        ei = O.batch_edge_index(NODES, g)
+        O.posenet_forward(sd, x, ei, IMG, 2)             # warm-up
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.posenet_forward(sd, x, ei, IMG, 2)
+            ts.append(time.perf_counter() - t0)
+        med = sorted(ts)[1]
+        per_graph = med / g
+        cells.append({"threads": threads, "graphs_per_forward": g, "median_s": round(med, 4), "timed_forwards": 3,
+                      "graphs_per_s": round(g / med, 3)})
+    print(json.dumps({"cells": cells, "seconds": time.perf_counter() - t_start}), flush=True)
 
 
 def cpu_baseline(budget_s: float):
-    """The CPU oracle at the configuration that is FASTEST on the GPU box's host (2x EPYC 9575F, 128 cores), measured
-    with tests/probes/cpu_threads_probe.py and this function: one process x 32 torch threads = 12.1 graphs/s; 16 threads 10.7;
-    64 threads 7.1; 128 threads 3.3; 256 threads 0.1; four concurrent 32-thread processes 8.0 in total (memory-bound
-    oneDNN convolutions do not scale across the sockets).  Started as a child process BEFORE this process touches the
-    GPU; `cores` reports the threads actually used."""
+    """SURVEY 8(d) protocol: the CPU oracle (validated against the reference in the build container: "port") with
+    torch.set_num_threads(k) for k = all physical cores of this box, k = 8 (comparable with the build container) and
+    k = 32 (the optimum measured on the 2 x EPYC 9575F GPU host: oneDNN convolutions are memory-bound and do not scale
+    across the sockets -- 128 threads 3.3 graphs/s, 64: 7.1, 32: 12.1, 16: 10.7); B = 1 / 8 / 32 graphs per forward,
+    1 warm-up + median of 3.  One child process per thread count, all BEFORE this process touches the GPU.  `value` = the
+    fastest cell, `cores` = its thread count, the rest is under `sweep`.  ``budget_s`` bounds the whole leg."""
     import subprocess
-    phys = max(1, (os.cpu_count() or 2) // 2)
-    workers = 1
-    threads = min(CPU_THREADS_PER_WORKER, phys)
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(budget_s), str(threads)],
-                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for _ in range(workers)]
-    total, secs, n_graphs = 0.0, 0.0, 0
-    for p in procs:
-        out, _ = p.communicate(timeout=budget_s * 6 + 300)
-        r = json.loads(out.strip().splitlines()[-1])
-        total += r["graphs"] / r["seconds"]
-        secs = max(secs, r["seconds"])
-        n_graphs += r["graphs"]
-    return {"value": round(total, 3), "unit": "graphs/s", "cores": workers * threads, "kind": "port",
-            "sample": f"{workers} concurrent processes x {threads} torch threads, {n_graphs} graphs in 4-graph forwards "
-                      f"(32 images 224x224 each), torch {torch.__version__} CPU fp32, {secs:.1f} s"}
+    phys = physical_cores()
+    counts = []
+    for k in (min(CPU_THREADS_BEST, phys), min(8, phys), phys):      # cheapest first; the all-cores run gets what is left
+        if k not in counts:
+            counts.append(k)
+    t0 = time.perf_counter()
+    sweep, secs = [], 0.0
+    for i, k in enumerate(counts):
+        left = budget_s - (time.perf_counter() - t0)
+        share = max(5.0, left / (len(counts) - i))
+        env = dict(os.environ, OMP_NUM_THREADS=str(k), MKL_NUM_THREADS=str(k))
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(share), str(k)],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
+        try:
+            out, _ = p.communicate(timeout=share * 3 + 240)
+            r = json.loads(out.strip().splitlines()[-1])
+            sweep += r["cells"]
+            secs += r["seconds"]
+        except Exception as exc:                                     # a baseline leg must not take the bench down
+            p.kill()
+            sweep.append({"threads": k, "skipped": f"worker failed: {type(exc).__name__}"})
+    done = [c for c in sweep if "graphs_per_s" in c]
+    if not done:
+        return None
+    best = max(done, key=lambda c: c["graphs_per_s"])
+    return {"value": best["graphs_per_s"], "unit": "graphs/s", "cores": best["threads"], "kind": "port",
+            "physical_cores": phys,
+            "sample": f"oracle forward (torch {torch.__version__} CPU fp32) of {best['graphs_per_forward']} 8-node graphs "
+                      f"(= {8 * best['graphs_per_forward']} images 224x224) per call, {best['threads']} threads, 1 warm-up + median "
+                      f"of 3; fastest of the sweep threads in {counts} x graphs-per-forward in (1, 8, 32); {secs:.0f} s of CPU work",
+            "sweep": sweep}
 
 
 def spawn_ranks(n: int, script: str = None, argv=None) -> int:
@@ -120,6 +170,10 @@ def spawn_ranks(n: int, script: str = None, argv=None) -> int:
         port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), script or os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: RCCL shares device buffers between the ranks' processes through HIP IPC handles, and the
+    # host driver of this GPU pool only supports the dmabuf flavour (with the legacy mode hipIpcGetMemHandle fails with
+    # "invalid argument" and init_process_group / the first collective dies).  The image exports it already; it is set
+    # here (never overriding a value the caller chose) so that the ranks get it even from a scrubbed environment.
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None
@@ -138,8 +192,8 @@ def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-worker":
         return cpu_worker(float(sys.argv[2]), int(sys.argv[3]))
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(spawn_ranks(args.gpus))
+    if (args.gpus > 1 or args.launcher) and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, argv=[a for a in sys.argv[1:] if a != "--launcher"]))
     cpu_line = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.cpu_baseline_seconds > 0:
         cpu_line = cpu_baseline(args.cpu_baseline_seconds)      # child processes, before any GPU initialisation here
@@ -153,7 +207,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # under a launcher (torchrun environment) the process group is RCCL at ANY world size, 1 included: the collective of
+    # the step then really runs (`python bench.py --gpus 1 --launcher` is how a one-GPU box covers the N > 1 code path)
+    under_launcher = "WORLD_SIZE" in os.environ
+    if under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -189,8 +246,8 @@ def main():
 
     def step():
         _, rel, _ = model(data)
-        if world > 1:
-            return gather_rows(rel.view(B, NODES * (NODES - 1), 6), counts)
+        if under_launcher:
+            return gather_rows(rel.view(B, NODES * (NODES - 1), 6), counts, always=True)
         return rel
 
     for _ in range(max(args.warmup, 1)):
@@ -199,14 +256,14 @@ def main():
 
     def timed(n_steps):
         nonlocal out
-        if world > 1:
+        if under_launcher:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_steps):
             out = step()
         torch.cuda.synchronize()
-        if world > 1:
+        if under_launcher:
             dist.barrier()
         return time.perf_counter() - t0
 
@@ -250,7 +307,7 @@ def main():
                        "what": f"the same kernel alone at {gi} graphs per launch ({round(v['work'] / v['launches'] / 1e6)} MB "
                                "algorithmic, back-to-back launches on one stream)"}
         del msg, gp, big
-    if world > 1:
+    if under_launcher:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -270,7 +327,10 @@ def main():
                        "graphs_per_step_per_gpu": B, "nodes_per_graph": NODES, "edges_per_graph": NODES * (NODES - 1),
                        "image": [IMG, IMG], "streams_per_gpu": args.streams,
                        "parallelism": f"graph-sharded x{world}: one process per GPU, RCCL world_size={world}, weights replicated, "
-                                      "one all-gather of the rel poses per step (no other collective)"},
+                                      "one all-gather of the rel poses per step (no other collective)",
+                       "process_group": (f"nccl (RCCL), world_size={world}: barrier + all_gather_into_tensor per step + all_reduce(MAX) "
+                                         "of the elapsed time executed") if under_launcher else
+                                        "none (plain single process: no launcher environment, the step ends at the rel poses)"},
         }
         if kt is not None and args.encoder_dtype == "bf16" and kt["conv"]["launches"]:
             c = kt["conv"]
@@ -366,7 +426,7 @@ def main():
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if under_launcher:
         dist.barrier()
         dist.destroy_process_group()
 

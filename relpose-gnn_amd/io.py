@@ -47,9 +47,10 @@ _SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "
 # execute code when called from a REDUCE opcode.
 _SAFE_GLOBALS = {
     ("collections", "OrderedDict"), ("collections", "defaultdict"),
+    ("_codecs", "encode"),                 # how pickle protocol 2 (torch.save's default) writes a `bytes` object: pure data
     ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
     ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
-    ("torch.storage", "_load_from_bytes"), ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
+    ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
     ("torch", "Size"), ("torch", "device"), ("torch", "dtype"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
     ("torch.serialization", "_get_layout"),
     ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
@@ -62,14 +63,25 @@ _TORCH_DTYPES = {"float32", "float64", "float16", "bfloat16", "int64", "int32", 
                  "complex64", "complex128", "float", "double", "half", "long", "int", "short"}
 
 
+def _load_from_bytes_checked(b):
+    """Stand-in for ``torch.storage._load_from_bytes`` (what a storage pickled on its own reduces to).  The original
+    calls ``torch.load(io.BytesIO(b), weights_only=False)`` with the DEFAULT pickle module, i.e. a REDUCE of it on attacker
+    bytes runs arbitrary code; here the nested stream goes through the same allow-list as the outer one."""
+    import io
+    return torch.load(io.BytesIO(b), map_location="cpu", pickle_module=_PickleModule, weights_only=False)
+
+
 class _Unpickler(pickle.Unpickler):
     """PyG classes -> neutral shells; apart from those only an explicit allow-list of tensor-rebuilding helpers, typed
     storages, dtypes and plain containers resolves.  A sample file is data: a pickle that names anything else (any
-    callable that could run code from a REDUCE opcode) is refused."""
+    callable that could run code from a REDUCE opcode) is refused; ``torch.storage._load_from_bytes`` (which unpickles
+    its argument with the unrestricted default module) is replaced by a wrapper that applies this allow-list again."""
 
     def find_class(self, module: str, name: str):
         if module == "torch_geometric" or module.startswith("torch_geometric."):
             return type(name, (_Shell,), {"__module__": module})
+        if (module, name) == ("torch.storage", "_load_from_bytes"):
+            return _load_from_bytes_checked
         if ((module, name) in _SAFE_GLOBALS or (module == "builtins" and name in _SAFE_BUILTINS) or
                 (module == "torch" and (name in _TORCH_STORAGES or name in _TORCH_DTYPES))):
             return super().find_class(module, name)

@@ -35,7 +35,7 @@ import torch.nn.functional as F
 from . import _lib as _L
 from . import ops
 from .params import pack_gnn, pack_gnn_bf16
-from .resnet import EncoderRunner
+from .resnet import EncoderRunner, WorkspacePool
 
 
 class AttentionBlock(nn.Module):
@@ -118,14 +118,14 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         # groups on the same slot run one after the other.  None = `hip_streams` equal contiguous groups, one per stream.
         self.stream_schedule: Optional[List[Tuple[int, int, int]]] = None
         self._streams: List[torch.cuda.Stream] = []
-        self._enc = EncoderRunner()
+        self._ws_pool = WorkspacePool()            # one buffer per stream slot, shared by the encoder and the GNN call
+        self._enc = EncoderRunner(self._ws_pool)
         self._gnn_packed: Optional[List[torch.Tensor]] = None
         self._gnn_ptrs = None
         self._gnn_bf16: Optional[List[torch.Tensor]] = None
         self._gnn_bf16_ptrs = None
         self._gnn_dtype = "f32"
         self._extra: Dict[str, torch.Tensor] = {}
-        self._gnn_ws: Dict[Tuple, torch.Tensor] = {}
         self.index_check = "deferred"            # "deferred" | "sync" (see the module docstring)
         self._status: Optional[torch.Tensor] = None          # device int32 [8]: bad-edge counters, one per stream slot
         self._status_host: Optional[torch.Tensor] = None     # pinned mirror
@@ -162,7 +162,7 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         self._gnn_packed, self._gnn_ptrs = None, None
         self._gnn_bf16, self._gnn_bf16_ptrs = None, None
         self._extra = {}
-        self._gnn_ws.clear()
+        self._ws_pool.clear()
 
     def _apply(self, fn, *a, **k):
         if hasattr(self, "_enc"):
@@ -262,14 +262,9 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
 
     def _gnn_call(self, lib, feat, esrc_ptr, edst_ptr, node_off, n, e, abs_pose, rel_pose, node_f, edge_f, status, slot):
         d = feat.shape[1]
-        key = (n, e, d, feat.device)
-        ent = self._gnn_ws.get(slot)
-        if ent is None or ent[0] != key:
-            skew = ((slot[0] + 3 * slot[1]) % 7 if isinstance(slot, tuple) else int(slot) % 7) * 132 * 1024      # see resnet.EncoderRunner: de-aliases the slots
-            raw = torch.empty(lib.rpg_gnn_workspace_bytes(n, e, d) + skew, dtype=torch.uint8, device=feat.device)
-            ent = (key, raw[skew:])
-            self._gnn_ws[slot] = ent
-        ws = ent[1]
+        # the slot's workspace (resnet.WorkspacePool): the SAME buffer the encoder call of this slot used a moment ago on
+        # this stream -- stream order makes the reuse safe, and the split-K scratch slice exists once per slot
+        ws = self._ws_pool.get(slot, lib.rpg_gnn_workspace_bytes(n, e, d), feat.device)
         if self._gnn_dtype == "bf16":
             rc = lib.rpg_gnn_forward_bf16(self._gnn_ptrs, len(self._gnn_packed), self._gnn_bf16_ptrs, len(self._gnn_bf16),
                                           feat.data_ptr(), esrc_ptr, edst_ptr, node_off, n, e, d, int(self.gnn_recursion),
@@ -339,13 +334,19 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
                 cn.append(cn[-1] + a)
                 ce.append(ce[-1] + b)
             out = []
-            covered = 0
             for g0, g1, slot in self.stream_schedule:
                 if not (0 <= g0 < g1 <= len(nodes)) or not (0 <= slot < 8):
                     raise ValueError("stream_schedule: groups must be non-empty ranges of graphs, slots 0..7")
                 out.append((cn[g0], cn[g1], ce[g0], ce[g1], slot))
-                covered += g1 - g0
-            if covered != len(nodes):
+            # exact-once coverage: sorted by first graph, every group starts where the previous one ended (equal lengths
+            # alone would let (0,2),(1,3) through: rows 0..0 computed twice on racing streams, row 3 never written)
+            nxt = 0
+            for g0, g1, _ in sorted(self.stream_schedule):
+                if g0 != nxt:
+                    raise ValueError("stream_schedule must cover every graph of the batch exactly once "
+                                     f"(gap or overlap at graph {min(g0, nxt)})")
+                nxt = g1
+            if nxt != len(nodes):
                 raise ValueError("stream_schedule must cover every graph of the batch exactly once")
             return out
         out, g0, n0, e0 = [], 0, 0, 0
@@ -418,7 +419,11 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
             if self.use_AP:
                 abs_pose = ops.pose_heads(node_f, t[18], t[19])
         if not self.use_AP:                                                       # posenet.py:1080-1083
-            lo, hi = torch.minimum(ei[0], ei[1]), torch.maximum(ei[0], ei[1])     # index plumbing (compute_edge_features)
+            # index plumbing (compute_edge_features).  Clamped like the GNN's own copy of the end points (rpg_graph_prepare):
+            # with index_check="deferred" an out-of-range node id is REPORTED by the device-side counter (IndexError at the
+            # next look), and must not become an out-of-bounds row read of this gather in the meantime
+            lo = torch.minimum(ei[0], ei[1]).clamp_(0, n - 1)
+            hi = torch.maximum(ei[0], ei[1]).clamp_(0, n - 1)
             abs_pose = ops.linear_gather([(node_f, lo), (node_f, hi)], self._extra["heads_pair_w"],
                                          self._extra["heads_pair_b"], e)
         return abs_pose, rel_pose, (edge_index_knn if k is not None else edge_index)

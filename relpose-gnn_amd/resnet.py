@@ -39,18 +39,44 @@ class BasicBlock(nn.Module):
         raise RuntimeError("BasicBlock is a parameter container; call the enclosing ResNet / PoseNetX_R2")
 
 
+class WorkspacePool:
+    """Caller-owned workspaces of the composite C calls, one per concurrent stream slot.  The encoder call and the GNN call
+    of a slot run back to back on ONE stream and neither reads what the other left in its workspace (the features travel
+    in their own tensor), so both get the SAME buffer, sized for the larger request: the 96-MB split-K / stream-K scratch
+    slice that each workspace carries is then held once per slot instead of once per call kind, and the GNN's
+    buffers cost nothing on top of the encoder's."""
+
+    def __init__(self):
+        self._buf: Dict[object, torch.Tensor] = {}
+
+    def clear(self) -> None:
+        self._buf.clear()
+
+    def get(self, slot, nbytes: int, device) -> torch.Tensor:
+        # concurrent stream slots get workspaces that start at different offsets within a 2-MiB window: torch hands
+        # out 2-MiB-aligned blocks and identically laid-out workspaces would put both streams on the same HBM channels
+        skew = ((slot[0] + 3 * slot[1]) % 7 if isinstance(slot, tuple) else int(slot) % 7) * 132 * 1024
+        raw = self._buf.get(slot)
+        if raw is None or raw.device != device or raw.numel() < nbytes + skew:
+            if raw is not None and raw.device == device:
+                nbytes = max(nbytes, raw.numel() - skew)      # never shrink: the other call kind of this slot still fits
+            raw = torch.empty(nbytes + skew, dtype=torch.uint8, device=device)
+            self._buf[slot] = raw
+        return raw[skew:]
+
+
 class EncoderRunner:
     """Packs an encoder state dict for the C ABI and runs it; shared by ``ResNet.forward`` and ``PoseNetX_R2``."""
 
-    def __init__(self):
+    def __init__(self, pool: Optional[WorkspacePool] = None):
         self._packed: Optional[Tuple[List[torch.Tensor], List[int], List[int]]] = None
         self._ptrs = None
-        self._ws: Dict[Tuple, torch.Tensor] = {}
+        self._pool = pool if pool is not None else WorkspacePool()
         self.dtype = "f32"          # "f32": Winograd / direct f32 MFMA kernels; "bf16": bf16 activations + bf16 MFMA
 
     def invalidate(self) -> None:
         self._packed, self._ptrs = None, None
-        self._ws.clear()
+        self._pool.clear()
 
     def set_dtype(self, dtype: str) -> None:
         if dtype not in ("f32", "bf16"):
@@ -88,18 +114,9 @@ class EncoderRunner:
         n, _, h, w = x.shape
         feat_dim = tensors[-2].shape[0]
         planes_c = L.int_array(planes)
-        key = (n, h, w, x.device)
         bf16 = self.dtype == "bf16"
-        ent = self._ws.get(slot)          # one workspace per concurrent stream slot, kept for the last shape seen
-        if ent is None or ent[0] != key:
-            nbytes = (lib.rpg_resnet_bf16_workspace_bytes if bf16 else lib.rpg_resnet_workspace_bytes)(n, h, w, planes_c)
-            # concurrent stream slots get workspaces that start at different offsets within a 2-MiB window: torch hands
-            # out 2-MiB-aligned blocks and identically laid-out workspaces would put both streams on the same HBM channels
-            skew = ((slot[0] + 3 * slot[1]) % 7 if isinstance(slot, tuple) else int(slot) % 7) * 132 * 1024
-            raw = torch.empty(nbytes + skew, dtype=torch.uint8, device=x.device)
-            ent = (key, raw[skew:])
-            self._ws[slot] = ent
-        ws = ent[1]
+        nbytes = (lib.rpg_resnet_bf16_workspace_bytes if bf16 else lib.rpg_resnet_workspace_bytes)(n, h, w, planes_c)
+        ws = self._pool.get(slot, nbytes, x.device)      # one workspace per concurrent stream slot (grows, never shrinks)
         feat = torch.empty((n, feat_dim), dtype=torch.float32, device=x.device)
         fwd = lib.rpg_resnet_forward_bf16 if bf16 else lib.rpg_resnet_forward_f32
         rc = fwd(self._ptrs, len(tensors), L.int_array(blocks), planes_c, feat_dim, x.data_ptr(), n, h, w, feat.data_ptr(),

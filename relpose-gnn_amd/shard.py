@@ -26,12 +26,14 @@ def shard_counts(n_graphs: int, world: int) -> List[int]:
     return [shard_range(n_graphs, r, world)[1] - shard_range(n_graphs, r, world)[0] for r in range(world)]
 
 
-def gather_rows(local: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
+def gather_rows(local: torch.Tensor, counts: List[int], group=None, always: bool = False) -> torch.Tensor:
     """All-gather per-rank row blocks of unequal length: ``local`` is [counts[rank], ...]; returns the concatenation
     [sum(counts), ...] in rank order on every rank.  Ragged tails are zero-padded to max(counts) for the collective
-    (one ``all_gather_into_tensor``) and trimmed afterwards."""
+    (one ``all_gather_into_tensor``) and trimmed afterwards.  A single rank returns ``local`` itself unless ``always`` is
+    set and a process group exists: then the (RCCL) collective runs at world size 1 too, which is how the one-GPU box
+    exercises the multi-GPU step (bench.py under its own launcher, tests/test_hip_rccl.py)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (always and dist.is_initialized()):
         return local
     rank = dist.get_rank(group)
     assert local.shape[0] == counts[rank], (local.shape, counts, rank)

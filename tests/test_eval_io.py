@@ -160,6 +160,33 @@ def test_graph_reader_without_pyg(tmp_path, layout):
         rio.load_graph(str(evil))
     assert "refusing to unpickle torch.utils.collect_env.run" in str(exc.value) and not (tmp_path / "pwned").exists()
 
+    class _Nested:                                                      # torch.storage._load_from_bytes unpickles its
+        def __reduce__(self):                                           # argument with the DEFAULT module -> nested gadget
+            import pickle
+            import torch.storage as ts
+
+            class _Inner:
+                def __reduce__(self_inner):
+                    return (os.system, ("echo PWNED > " + str(tmp_path / "pwned2"),))
+            return (ts._load_from_bytes, (pickle.dumps(_Inner()),))
+    for reader in (rio.load_graph, rio.load_checkpoint_state_dict):
+        torch.save({"x": x, "edge_index": ei, "f": _Nested()}, evil)
+        with pytest.raises(Exception):
+            reader(str(evil))
+        assert not (tmp_path / "pwned2").exists()
+    # the legitimate use of that helper (a storage / tensor pickled on its own inside the file) still loads
+    import pickle
+    import torch.storage as ts
+
+    class _Legit:
+        def __reduce__(self):
+            import io
+            buf = io.BytesIO()
+            torch.save(torch.arange(5.0), buf)
+            return (ts._load_from_bytes, (buf.getvalue(),))
+    torch.save({"x": x, "edge_index": ei, "t": _Legit()}, evil)
+    assert torch.equal(rio.load_checkpoint_state_dict(str(evil))["t"], torch.arange(5.0))
+
 
 def test_checkpoint_reader(tmp_path):
     from relpose_gnn_amd import io as rio

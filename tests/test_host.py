@@ -167,6 +167,17 @@ def test_stream_partition_from_pyg_batch_tables():
     assert m._partition(pyg2, n, e) == [(0, 24, 0, 168, 0), (24, 48, 168, 336, 1)]
     assert m._partition(types.SimpleNamespace(x=ref.x[:8], edge_index=ref.edge_index[:, :56], batch=ref.batch[:8],
                                               num_graphs=1), 8, 56) is None
+    # explicit schedules must cover every graph exactly once (equal total length is not enough)
+    m.stream_schedule = [(0, 2, 0), (2, 6, 1)]
+    assert m._partition(pyg2, n, e) == [(0, 16, 0, 112, 0), (16, 48, 112, 336, 1)]
+    m.stream_schedule = [(3, 6, 1), (0, 3, 0)]                     # issue order is the caller's business
+    assert m._partition(pyg2, n, e) == [(24, 48, 168, 336, 1), (0, 24, 0, 168, 0)]
+    for bad in ([(0, 3, 0), (2, 5, 1)], [(0, 2, 0), (1, 3, 1), (3, 6, 0)], [(0, 3, 0), (4, 6, 1)], [(0, 3, 0), (3, 5, 1)],
+                [(0, 4, 0), (2, 4, 1), (4, 6, 1)]):
+        m.stream_schedule = bad
+        with pytest.raises(ValueError):
+            m._partition(pyg2, n, e)
+    m.stream_schedule = None
 
 
 def test_stem_pair_table_matches_the_kernel():
