@@ -79,26 +79,128 @@ def errors(pred_poses: np.ndarray, targ_poses: np.ndarray) -> EvalResult:
     return EvalResult(pred_poses, targ_poses, t_loss, q_loss)
 
 
+class _InputPipeline:
+    """Host -> device staging of the node images of an evaluation stream, double buffered.
+
+    The reference's loader hands over one graph at a time from pinned memory (``DataLoader(..., pin_memory=True)``,
+    testing/test.py:193) and copies it with ``data.to(device)`` (:211).  Here a micro-batch of graphs is collated straight
+    into one of TWO pinned host buffers (a ``copy_`` per graph: no ``torch.cat`` temporary, no pageable H2D), sent to one of
+    two device buffers on a dedicated copy stream, and the forward of micro-batch i runs while micro-batch i+1 is being
+    collated and copied.  Events order the three parties: ``sent[k]`` (copy stream: buffer k is on the device; the host may
+    refill the pinned half, the compute stream may read the device half) and ``used[k]`` (compute stream: the forward that
+    read device buffer k is done; the copy stream may overwrite it).  Graphs whose ``x`` is already pinned skip the staging
+    copy; graphs already on the device skip the pipeline altogether (``evaluate_stream`` collates them on the device)."""
+
+    def __init__(self, device, rows: int, row_floats: int):
+        self.device = device
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.host = [torch.empty((rows, row_floats), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        self.dev = [torch.empty((rows, row_floats), dtype=torch.float32, device=device) for _ in range(2)]
+        self.sent = [torch.cuda.Event() for _ in range(2)]
+        self.used = [torch.cuda.Event() for _ in range(2)]
+        self.n_sent = [0, 0]
+
+    def fits(self, rows: int, row_floats: int) -> bool:
+        return rows <= self.host[0].shape[0] and row_floats == self.host[0].shape[1]
+
+    def stage(self, k: int, chunk) -> torch.Tensor:
+        """Collate the chunk's node images into pinned buffer k and enqueue the H2D copy; returns the device view."""
+        if self.n_sent[k]:
+            self.sent[k].synchronize()                 # the previous copy out of pinned buffer k has left the host
+        host, dev, off = self.host[k], self.dev[k], 0
+        direct = []                                    # graphs whose x is already pinned: copied from where they are
+        for g in chunk:
+            n = g.x.shape[0]
+            if g.x.is_pinned():
+                direct.append((off, n, g.x))
+            else:
+                host[off:off + n].copy_(g.x)
+            off += n
+        with torch.cuda.stream(self.copy_stream):
+            if self.n_sent[k]:
+                self.copy_stream.wait_event(self.used[k])      # the forward that read device buffer k has finished
+            if direct:
+                lo = 0
+                for o, n, src in direct:
+                    if o > lo:
+                        dev[lo:o].copy_(host[lo:o], non_blocking=True)
+                    dev[o:o + n].copy_(src, non_blocking=True)
+                    lo = o + n
+                if off > lo:
+                    dev[lo:off].copy_(host[lo:off], non_blocking=True)
+            else:
+                dev[:off].copy_(host[:off], non_blocking=True)
+            self.sent[k].record(self.copy_stream)
+        self.n_sent[k] += 1
+        return dev[:off]
+
+    def acquire(self, k: int) -> None:
+        torch.cuda.current_stream().wait_event(self.sent[k])
+
+    def release(self, k: int) -> None:
+        self.used[k].record(torch.cuda.current_stream())
+
+
+def _collate_on_device(chunk: Sequence[Data], x_dev: torch.Tensor, device) -> Batch:
+    """The PyG collation of ``chunk`` (graph.Batch.from_data_list) with the node images already on the device in ``x_dev``:
+    only the index tensors are built on the host (a few KB) and copied."""
+    eis, bs, off = [], [], 0
+    for gi, g in enumerate(chunk):
+        n = g.x.shape[0]
+        eis.append(g.edge_index + off)
+        bs.append(torch.full((n,), gi, dtype=torch.int64))
+        off += n
+    out = Batch(x=x_dev, edge_index=torch.cat(eis, 1).to(device, non_blocking=True), y=None, edge_attr=None,
+                batch=torch.cat(bs, 0).to(device, non_blocking=True))
+    out.graph_sizes = ([g.x.shape[0] for g in chunk], [int(g.edge_index.shape[1]) for g in chunk])
+    return out
+
+
 @torch.no_grad()
 def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64, pose_m=(0.0, 0.0, 0.0),
-                    pose_s=(1.0, 1.0, 1.0), ref_node: int = 0, rank: int = 0, world: int = 1) -> EvalResult:
+                    pose_s=(1.0, 1.0, 1.0), ref_node: int = 0, rank: int = 0, world: int = 1,
+                    stats: Optional[dict] = None) -> EvalResult:
     """Run ``model`` over a stream of single-graph ``Data`` objects (x, edge_index, y) and post-process like test.py.
     With world > 1 every rank evaluates its contiguous block (shard_range) and the [G,7] rows are all-gathered.
 
-    The loop is software-pipelined: the forward of micro-batch i+1 is enqueued (and its relative poses copied to pinned
-    host memory asynchronously) before the host post-processes micro-batch i, so the numpy work of test.py:213-251
-    overlaps the GPU instead of idling it."""
+    The loop is a three-stage software pipeline: while the GPU runs the forward of micro-batch i, the host collates
+    micro-batch i+1 into pinned memory and the copy stream sends it (``_InputPipeline``; graphs that already live on the
+    device are collated there instead), and once both are enqueued the host post-processes micro-batch i-1, whose relative
+    poses have come back through an asynchronous copy -- so neither the H2D transfer of the images (537 MB per 64 graphs
+    at 256x341), nor the D2H of the poses, nor the numpy work of test.py:213-251 leaves the GPU idle.
+    ``stats`` (optional dict) receives ``h2d_bytes`` and ``staged_graphs``."""
     from .shard import gather_rows, shard_counts, shard_range
     pose_m, pose_s = np.asarray(pose_m, dtype=np.float64), np.asarray(pose_s, dtype=np.float64)
     lo, hi = shard_range(len(graphs), rank, world)
     on_gpu = torch.device(device).type == "cuda"
     preds: List[np.ndarray] = []
     targs: List[np.ndarray] = []
+    pipe: Optional[_InputPipeline] = None
+    n_batches = 0
+    h2d_bytes = 0
 
     def launch(b0):
+        nonlocal pipe, n_batches, h2d_bytes
         chunk = [graphs[i] for i in range(b0, min(hi, b0 + micro_batch))]
-        batch = Batch.from_data_list(chunk).to(device, non_blocking=True)
+        k = n_batches & 1
+        n_batches += 1
+        staged = on_gpu and not any(g.x.is_cuda for g in chunk)
+        if staged:
+            rows, width = sum(g.x.shape[0] for g in chunk), int(chunk[0].x.shape[1])
+            if pipe is None or not pipe.fits(rows, width):
+                if pipe is not None:
+                    torch.cuda.synchronize(device)                  # a larger buffer pair replaces one that is in flight
+                cap = max(rows, max(g.x.shape[0] for g in chunk) * micro_batch)
+                pipe = _InputPipeline(torch.device(device), cap, width)
+            x_dev = pipe.stage(k, chunk)
+            h2d_bytes += x_dev.numel() * 4
+            batch = _collate_on_device(chunk, x_dev, device)
+            pipe.acquire(k)
+        else:
+            batch = Batch.from_data_list(chunk).to(device, non_blocking=True)
         _, rel, edge_index = model(batch)
+        if staged:
+            pipe.release(k)
         # a model-built edge list (kNN graph: the reference's default --knn 4, test.py:308, posenet.py:1047-1048) comes
         # back instead of the stored one: it travels to the host with the poses and is cut per graph in finish()
         model_built = edge_index is not batch.edge_index
@@ -152,6 +254,9 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
         finish(pending)
     if getattr(model, "check_edge_index", None) is not None:
         model.check_edge_index()                       # everything has been issued: wait for the last report
+    if stats is not None:
+        stats["h2d_bytes"] = h2d_bytes
+        stats["micro_batches"] = n_batches
     pred = np.stack(preds) if preds else np.zeros((0, 7))
     targ = np.stack(targs) if targs else np.zeros((0, 7))
     if world > 1:

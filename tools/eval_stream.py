@@ -8,8 +8,11 @@ ranks of one node and collated with one all-gather (RCCL) of the derived query p
     ... --graphs 17000 --encoder-dtype bf16                                        # configs[4]: all seven scenes, bf16 encoder
 
 Pixels are synthetic (no dataset here); the edge lists are the reference's fully-connected 8-node graphs; every graph
-goes through the same post-processing as testing/test.py:213-251 (`relpose_gnn_amd.evaluate`).  The reference evaluates
-with batch_size=1; graphs are independent, so they are micro-batched here (--micro-batch).  Prints one JSON line."""
+goes through the same post-processing as testing/test.py:213-251.  The loop is the PRODUCT's: this script only builds the
+stream (host-resident single-graph `Data` objects, as the reference's loader delivers them, test.py:193,211) and calls
+`relpose_gnn_amd.evaluate.evaluate_stream`, which micro-batches (the reference evaluates with batch_size=1; graphs are
+independent), stages the node images through pinned double buffers on a copy stream, and overlaps D2H + post-processing.
+`--input resident` keeps the images on the device (no H2D) for comparison.  Prints one JSON line."""
 import argparse
 import json
 import os
@@ -32,6 +35,10 @@ def main():
     ap.add_argument("--knn", type=int, default=-1, help="the reference's --knn (test.py:308 defaults to 4): the model rebuilds "
                     "the graph from the encoder features (posenet.py:1047-1048); -1 = the stored fully-connected edges")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="rpg_set_tuning(KEY, VALUE) before the run (A/B)")
+    ap.add_argument("--input", choices=("host", "pinned", "resident"), default="host",
+                    help="where the graphs' node images live when the stream starts: pageable host memory (a plain loader), pinned "
+                         "host memory (DataLoader(pin_memory=True), test.py:193), or the device (no H2D: the comparison point)")
+    ap.add_argument("--pool", type=int, default=96, help="distinct graphs' worth of synthetic pixels that the stream cycles through")
     args = ap.parse_args()
     h, w = (int(v) for v in args.shape.split("x"))
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -43,10 +50,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     import relpose_gnn_amd.synth as S
     from relpose_gnn_amd import evaluate as E
-    from relpose_gnn_amd.graph import fc_batch
     from relpose_gnn_amd.posenet import PoseNetX_R2
     from relpose_gnn_amd.resnet import resnet34
-    from relpose_gnn_amd.shard import gather_rows, shard_counts, shard_range
 
     D = 2048
     model = PoseNetX_R2(resnet34(), droprate=0.0, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D,
@@ -60,68 +65,30 @@ def main():
         k, v = kv.split("=")
         ops.set_tuning(int(k), int(v))
 
-    lo, hi = shard_range(args.graphs, rank, world)
+    # The stream: `--graphs` single-graph Data objects as a loader delivers them -- x on the HOST (pageable by default,
+    # `--input pinned` = a pin_memory loader, `--input resident` = already on the device: the no-H2D comparison point).
+    # Pixels are synthetic; `--pool` distinct graphs' worth of them are cycled (2000 distinct 256x341 graphs would be 17 GB).
+    from relpose_gnn_amd.graph import Data, fc_edge_index
+    gen = torch.Generator().manual_seed(77 + rank)
+    ei8 = fc_edge_index(8)
+    pool = []
+    for i in range(min(args.pool, args.graphs)):
+        xi = torch.randn((8, 3 * h * w), generator=gen)
+        if args.input == "pinned":
+            xi = xi.pin_memory()
+        elif args.input == "resident":
+            xi = xi.to(dev)
+        pool.append((xi, torch.randn((8, 6), generator=gen) * 0.3))            # pixels, ground-truth poses (t, log q)
+    graphs = [Data(x=pool[i % len(pool)][0], edge_index=ei8, y=pool[i % len(pool)][1]) for i in range(args.graphs)]
     mb = args.micro_batch
-    gen = torch.Generator(device=dev).manual_seed(77 + rank)
-    x = torch.randn((8 * mb, 3 * h * w), generator=gen, device=dev)           # pixel buffer reused by every micro-batch
-    y = torch.randn((8 * mb, 6), generator=gen, device=dev) * 0.3              # ground-truth poses (t, log q)
-    pm, ps = np.zeros(3), np.ones(3)
 
-    ei_local = None
-
-    def run(count):
-        """Software-pipelined like evaluate.evaluate_stream: enqueue micro-batch i+1, then post-process micro-batch i."""
-        nonlocal ei_local
-        preds, pending, done = [], None, 0
-        y_host = y.cpu().numpy()
-
-        def finish(item):
-            g, host, host_ei, ev = item
-            ev.synchronize()
-            model.check_edge_index(wait=False)           # this micro-batch's device-side index check landed with `ev`
-            rel_c = host.numpy()
-            if host_ei is not None:                      # model-built (kNN) edges: cut per graph by the target node's graph
-                ei = host_ei.numpy()
-                gid = ei[1] // 8
-                for k in range(g):
-                    cols = np.flatnonzero(gid == k)
-                    p, _ = E.query_pose(rel_c[cols], y_host[8 * k: 8 * (k + 1)], ei[:, cols] - 8 * k, pm, ps)
-                    preds.append(p)
-                return
-            for k in range(g):
-                p, _ = E.query_pose(rel_c[56 * k: 56 * (k + 1)], y_host[8 * k: 8 * (k + 1)], ei_local, pm, ps)
-                preds.append(p)
-
-        while done < count:
-            g = min(mb, count - done)
-            batch = fc_batch(x[: 8 * g], 8, y[: 8 * g])
-            if ei_local is None:
-                ei_local = batch.edge_index[:, :56].cpu().numpy()
-            _, rel, ei_out = model(batch)
-            host = torch.empty(rel.shape, dtype=rel.dtype, pin_memory=True)
-            host.copy_(rel, non_blocking=True)                                  # D2H as test.py:214 does, asynchronously
-            host_ei = None
-            if ei_out is not batch.edge_index:
-                host_ei = torch.empty(ei_out.shape, dtype=ei_out.dtype, pin_memory=True)
-                host_ei.copy_(ei_out, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            if pending is not None:
-                finish(pending)
-            pending = (g, host, host_ei, ev)
-            done += g
-        if pending is not None:
-            finish(pending)
-        model.check_edge_index()
-        return np.stack(preds) if preds else np.zeros((0, 7))
-
-    run(min(mb, hi - lo))                                                      # warm-up (packing, workspaces)
+    E.evaluate_stream(model, graphs[: min(2 * mb, len(graphs))], dev, micro_batch=mb)      # warm-up (packing, workspaces, staging buffers)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    stats = {}
     t0 = time.perf_counter()
-    local_pred = run(hi - lo)
-    poses = gather_rows(torch.from_numpy(local_pred).to(dev), shard_counts(args.graphs, world)) if world > 1 else local_pred
+    res = E.evaluate_stream(model, graphs, dev, micro_batch=mb, rank=rank, world=world, stats=stats)   # THE product loop
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -131,11 +98,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
-        assert len(poses) == args.graphs
-        print(json.dumps({"workload": f"eval-shape stream: {args.graphs} 8-node FC graphs, {h}x{w}, encoder {args.encoder_dtype}, GNN Linears {args.gnn_dtype}, "
-                                      f"knn {args.knn}, micro-batch {mb}, pipelined D2H + test.py post-processing per graph included",
-                          "n_gpus": world, "graphs": args.graphs, "seconds": round(dt, 3),
-                          "graphs_per_s": round(args.graphs / dt, 1)}), flush=True)
+        assert len(res.pred_poses) == args.graphs and np.isfinite(res.pred_poses).all()
+        print(json.dumps({"workload": f"eval-shape stream through relpose_gnn_amd.evaluate.evaluate_stream: {args.graphs} 8-node FC graphs, "
+                                      f"{h}x{w}, encoder {args.encoder_dtype}, GNN Linears {args.gnn_dtype}, knn {args.knn}, micro-batch {mb}, "
+                                      f"node images {args.input} ({'pinned double-buffered H2D on a copy stream' if args.input != 'resident' else 'no H2D'}), "
+                                      "D2H + test.py post-processing per graph included",
+                          "input": args.input, "n_gpus": world, "graphs": args.graphs, "seconds": round(dt, 3),
+                          "graphs_per_s": round(args.graphs / dt, 1),
+                          "h2d_gb_per_s": round(stats.get("h2d_bytes", 0) / dt / 1e9, 2)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
