@@ -270,9 +270,9 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
 #define RPG_TUNE_WINO_SPLIT 8     /* 1: split-K tail + fix-up for the 8-wave Winograd kernel (default) | 0: whole tiles only */
 #define RPG_TUNE_FAST_LOADER 7    /* 1: buffer-load loaders + interleaved main loop where eligible (default) | 0: general loaders */
 #define RPG_TUNE_WINOGRAD 4       /* 0: always the direct kernel | 1: use u_wino43 where given, kernel by size (default) |
-                                     2 / 3 / 4: as 1 but always the 4-wave single-image / 8-wave / 4-wave short-K Winograd kernel */
-#define RPG_TUNE_WINO_SHORT 12    /* auto mode: convolutions with at most this many input channels on chip-filling grids take the
-                                     short-K kernel (two 4-wave workgroups per CU, K step 8); default 0 = never (measured: no gain) */
+                                     2 / 3: as 1 but always the 4-wave single-image / the 8-wave Winograd kernel */
+#define RPG_TUNE_WINO_SHORT 12    /* retired in round 3 with the short-K Winograd kernel it selected (measured: no gain); the key is
+                                     still accepted (values >= 0) and ignored */
 #define RPG_TUNE_WINO_PERSIST 14  /* 1: launches with more 8-wave tiles than CUs run the persistent kernel (one workgroup per CU walks its
                                      tiles, loads pipelined across tiles; needs Cin % 16 == 0) (default) | 2: also launches of at most one
                                      tile per CU (measured equal) | 0: one workgroup per tile */

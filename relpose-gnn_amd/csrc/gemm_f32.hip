@@ -385,7 +385,7 @@ extern "C" int rpg_set_tuning(int key, int value) {
         case RPG_TUNE_BF16_TILE: if (value < -1 || value > 3) return RPG_ERR_BAD_ARG; rpg::bf16_set_tile(value); return RPG_OK;
         case RPG_TUNE_BF16_FAST: rpg::bf16_set_fast(value != 0); return RPG_OK;
         case RPG_TUNE_FUSED_STEM: rpg::stem_pool_set(value != 0); return RPG_OK;
-        case RPG_TUNE_WINOGRAD: if (value < 0 || value > 4) return RPG_ERR_BAD_ARG; rpg::wino_set(value); return RPG_OK;
+        case RPG_TUNE_WINOGRAD: if (value < 0 || value > 3) return RPG_ERR_BAD_ARG; rpg::wino_set(value); return RPG_OK;
         case RPG_TUNE_WINO_PERSIST: if (value < 0 || value > 2) return RPG_ERR_BAD_ARG; rpg::wino_persist_set(value); return RPG_OK;
         case RPG_TUNE_WINO_SHORT: if (value < 0) return RPG_ERR_BAD_ARG; rpg::wino_short_set(value); return RPG_OK;
         default: return RPG_ERR_BAD_ARG;

@@ -20,7 +20,8 @@
 //   * wino43_conv8p_kernel (the one that matters: every launch with more tiles than CUs): the same K step in a persistent
 //     workgroup that walks its tiles with the load pipeline running across them;
 //   * wino43_conv_kernel: 4 waves on 64 tiles x 64 channels, one LDS image, two workgroups per CU: small grids;
-//   * wino43_conv4d_kernel: a measured-and-shelved short-K variant (two 4-wave workgroups per CU).
+// (A short-K variant with two 4-wave workgroups per CU, K step 8, was built, measured and removed in round 3: its K loop was
+// 6 % slower and ate what the overlap of one workgroup's prologue / epilogue with the other's MFMAs won)
 // The design rules come from tools/probes/mfma_shadow_probe.hip: VALU time does not hide behind f32 MFMAs on gfx950.
 //
 // Reference op replaced: nn.Conv2d(3x3, stride 1, pad 1) + nn.BatchNorm2d (eval) (+ identity) + ReLU of a torchvision
@@ -1052,224 +1053,6 @@ __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restr
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// The short-K kernel (layers 1-2: Cin <= 128, 12-24 K steps of 16 per tile): 4 waves on 64 tiles x 64 channels, K step 8,
-// TWO LDS images of 24 KB, one barrier per step, and TWO workgroups per CU.
-//
-// Why: with one 8-wave workgroup per CU nothing runs on the CU while that workgroup is in its prologue (a cold global
-// round trip) or epilogue (LDS transpose, residual round trip, stores): measured 10.7 k + 14.8 k cycles against 81 k of
-// K loop on layer 1 (profiles/r1_wino43_phase_cycles.txt), i.e. the matrix pipe idles a quarter of the time, and those
-// phases are latency, not instruction, bound (halving the epilogue's instruction count changed nothing).  Two independent
-// 4-wave workgroups per CU (one wave per SIMD each) drift out of phase, so one's prologue / epilogue runs under the
-// other's MFMAs.  The K step is 8 to make two double-buffered workgroups fit the 160-KB LDS (2 x 48 KB); per MFMA that
-// costs the same packed VALU (the input transform works on channel PAIRS: thread = (tile, 2 channels)), 4/3 of the
-// 8-wave kernel's load / LDS-write instructions, and twice its barriers.
-// MEASURED (round 2, in the model at 256 images): no gain -- layer 1 0.2881 vs 0.2867 ms average Winograd launch, layers
-// 1-2 0.2959; its K loop is ~6 % slower than the 8-wave kernel's (layers 3-4: 316 / 304 vs 297 / 286 us) and that eats what
-// the overlap wins; starting one of a CU's two workgroups 8-100 k cycles late (so that they cannot stay in phase) changed
-// nothing either.  Kept as a tested variant (RPG_TUNE_WINOGRAD = 4, RPG_TUNE_WINO_SHORT = max Cin), off by default.
-// Staging: thread t stages A row t>>2 (64 tiles), channel pair t&3 of the step's 8 channels: 6 pixels (8-byte loads) ->
-// 6 transformed pairs; and 3 of the 768 16-byte U chunks of the step (6 positions x 64 channels x 2 chunks).
-// LDS rows are 32 bytes (two 16-byte chunks, swapped on rows with bit 3 set: conflict-free ds_read_b128 / ds_write_b64).
-constexpr int NT4 = 256, BMT4 = 64, BK4 = 8;
-constexpr int A4_FLOATS = P * BMT4 * BK4, IMG4_FLOATS = A4_FLOATS + P * BN * BK4;      // 3072 + 3072 floats = 24 KB
-constexpr int LDS4_BYTES = 2 * IMG4_FLOATS * (int)sizeof(float);                      // 49,152 (>= 4 epilogue slabs of 9,216)
-
-struct F2 { f32x2 v; };
-__global__ __launch_bounds__(NT4, 2) void wino43_conv4d_kernel(const float* __restrict__ x, const float* __restrict__ U, int H,
-                                                              int W, int Cin, int Cout, int Tw, int M, Epi ep, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int K = 3 * Cin;
-    const int kpr = (Cin + BK4 - 1) / BK4;             // channel blocks of 8
-    const int nk = 3 * kpr;                            // K steps, channel-block major / kernel-row minor (see the 8-wave kernel)
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r8 = nwg & 7;
-    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
-    const int m0 = (tile / tiles_n) * BMT4;
-    const int n0 = (tile % tiles_n) * BN;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int row = tid >> 2, slot = tid & 3;          // A: tile-row `row` (0..63), channel pair `slot` of the step's 8
-    const int n_first = (m0 / Tw) / H;
-    const size_t img_floats = (size_t)H * W * Cin;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(x + n_first * img_floats) - (size_t)W * Cin, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, 0x7fffffff, 0x00020000);
-    constexpr unsigned OOB = 0x80000000u;
-    unsigned va[P], va3[3][P];
-    unsigned rowbits = 0;
-    {
-        const int m = m0 + row;
-        int img_off = 0, ho = 0, wi0 = -(1 << 24);
-        if (m < M) {
-            const int tw = m % Tw;
-            const int t = m / Tw;
-            ho = t % H;
-            img_off = (t / H - n_first) * (int)img_floats;
-            wi0 = 4 * tw - 1;
-            rowbits = (ho > 0 ? 1u : 0u) | 2u | (ho < H - 1 ? 4u : 0u);
-        }
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const int wi = wi0 + j;
-            va[j] = (unsigned)wi < (unsigned)W ? 4u * (unsigned)(img_off + (ho * W + wi) * Cin + 2 * slot) : OOB;
-        }
-    }
-    // U chunks of this thread: j = tid + 256 i, i = 0..2 -> position j / 128, channel row (j % 128) >> 1, 16-byte chunk j & 1
-    const unsigned ustride_b = (unsigned)Cout * K * 4u;
-    unsigned vb[3], vb_eff[3];
-    int st_b[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int j = tid + NT4 * i, pos = j >> 7, ch = (j & 127) >> 1, c = j & 1;
-        vb[i] = n0 + ch < Cout ? (unsigned)pos * ustride_b + 4u * (unsigned)((n0 + ch) * K + 4 * c) : OOB;
-        st_b[i] = A4_FLOATS + pos * BN * BK4 + ch * BK4 + 4 * (c ^ ((ch >> 3) & 1));
-    }
-    int f_kt = 0, f_c0 = 0;
-    const unsigned row_b = 4u * (unsigned)(W * Cin), krow_b = 4u * (unsigned)Cin;
-    auto refresh = [&]() {
-        asm volatile("" ::: "memory");
-        const bool live = f_kt < nk;
-        const bool cva = live && f_c0 + 2 * slot < Cin;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const bool rv = cva && ((rowbits >> kh) & 1u);
-#pragma unroll
-            for (int j = 0; j < P; ++j) va3[kh][j] = rv ? va[j] : OOB;
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) vb_eff[i] = live && f_c0 + 4 * ((tid + NT4 * i) & 1) < Cin ? vb[i] : OOB;
-    };
-    refresh();
-
-    f32x2 d[P];
-    float4 ub[3];
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    auto fetch_one = [&](int i, int kh) {             // i = 0..8: pixels 0..5 (8 bytes each), then the 3 U chunks
-        if (i < P) {
-            const unsigned sa = (unsigned)kh * row_b + 4u * (unsigned)f_c0;
-            d[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ra, va3[kh][i], sa, 0));
-        } else {
-            const unsigned sb = (unsigned)kh * krow_b + 4u * (unsigned)f_c0;
-            ub[i - P] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, vb_eff[i - P], sb, 0));
-        }
-    };
-    auto fetch_next = [&](int kh) {
-        ++f_kt;
-        if (kh == 2) {
-            f_c0 += BK4;
-            if (f_c0 + BK4 > Cin || f_kt >= nk) refresh();
-        }
-    };
-    // A row `row`, channel pair `slot`: chunk slot >> 1 (swapped on rows with bit 3 set), half slot & 1
-    const int st_a = row * BK4 + 4 * ((slot >> 1) ^ ((row >> 3) & 1)) + 2 * (slot & 1);
-    auto stage_one = [&](int p, int img) {
-        if (p >= P) {
-            *reinterpret_cast<float4*>(lds + img + st_b[p - P]) = ub[p - P];
-            return;
-        }
-        f32x2 v;
-        if (p == 0) v = pk_fma_p4(pk_sub(d[0], d[2]), pk_sub(d[4], d[2]));               // 4 d0 - 5 d2 + d4
-        else if (p == 5) v = pk_fma_m4(pk_sub(d[3], d[1]), pk_sub(d[5], d[3]));          // 4 d1 - 5 d3 + d5
-        else if (p <= 2) {
-            const f32x2 sx = pk_fma_m4(d[2], d[4]), tx = pk_fma_m4(d[1], d[3]);          // d4 - 4 d2, d3 - 4 d1
-            v = p == 1 ? pk_add(sx, tx) : pk_sub(sx, tx);
-        } else {
-            const f32x2 r = pk_sub(d[4], d[2]), t = pk_sub(d[3], d[1]);
-            v = p == 3 ? pk_fma_p2(t, r) : pk_fma_m2(t, r);                              // r +- 2 t
-        }
-        *reinterpret_cast<f32x2*>(lds + img + st_a + p * BMT4 * BK4) = v;
-    };
-
-    f32x16 acc[P];
-#pragma unroll
-    for (int xi = 0; xi < P; ++xi)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[xi][e] = 0.f;
-
-    // operand reads: lane (i = lane & 31, h = lane >> 5) reads the 16-byte chunk h of row i
-    const int rrow_a = wm * 32 + (lane & 31), rrow_b = wn * 32 + (lane & 31);
-    const int a_off = rrow_a * BK4 + 4 * ((lane >> 5) ^ ((rrow_a >> 3) & 1));
-    const int b_off = A4_FLOATS + rrow_b * BK4 + 4 * ((lane >> 5) ^ ((rrow_b >> 3) & 1));
-    float4 fa[2][2], fb[2][2];
-    auto frag_one = [&](int g, int set, int i, int img) {             // group g = positions 2g, 2g+1; i = 0..3: a0, b0, a1, b1
-        const int xi = 2 * g + (i >> 1);
-        if (i & 1) fb[set][i >> 1] = *reinterpret_cast<const float4*>(&lds[img + xi * BN * BK4 + b_off]);
-        else       fa[set][i >> 1] = *reinterpret_cast<const float4*>(&lds[img + xi * BMT4 * BK4 + a_off]);
-    };
-    // one K step (8 channels of one kernel row): 24 MFMAs in 3 groups of 8 = position pairs.  Behind MFMAs 0-3 of a group:
-    // the 4 operand reads of the next group (group 2: of the next step's group 0, from nxt).  Behind MFMAs 4-7 of groups 0-1:
-    // the 9 stage pieces of step kt+1 -> nxt (data loaded during step kt-1).  Behind the 8 MFMAs of group 2: the 9 buffer
-    // loads of step kt+2 into the same registers.  The barrier sits before the last group: by then every wave has written
-    // nxt and issued its last reads of cur.
-    auto kstep = [&](int cur, int nxt, int khf) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            // three groups per step: the operand register sets alternate over the groups of ALL steps, and a step's image
-            // parity is also the parity of its first group (3 s = s mod 2)
-            const int set = (g + (cur ? 1 : 0)) & 1, x0 = 2 * g;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int j = i & 1, e = i >> 1;
-                const float av = e == 0 ? fa[set][j].x : e == 1 ? fa[set][j].y : e == 2 ? fa[set][j].z : fa[set][j].w;
-                const float bv = e == 0 ? fb[set][j].x : e == 1 ? fb[set][j].y : e == 2 ? fb[set][j].z : fb[set][j].w;
-                acc[x0 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[x0 + j], 0, 0, 0);
-                if (i < 4) {
-                    if (g < 2) frag_one(g + 1, set ^ 1, i, cur);
-                    else frag_one(0, set ^ 1, i, nxt);
-                }
-                if (g < 2) {
-                    if (i >= 4) {
-                        const int s = 4 * g + (i - 4);                // pieces 0..7, plus piece 8 in the first slot
-                        stage_one(s, nxt);
-                        if (s == 0) stage_one(8, nxt);
-                    }
-                } else {
-                    fetch_one(i, khf);
-                    if (i == 7) fetch_one(8, khf);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (g == 1) {
-                __syncthreads();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        fetch_next(khf);
-    };
-
-#pragma unroll
-    for (int i = 0; i < 9; ++i) fetch_one(i, 0);
-    fetch_next(0);
-#pragma unroll
-    for (int p = 0; p < 9; ++p) stage_one(p, 0);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) fetch_one(i, 1);
-    fetch_next(1);
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) frag_one(0, 0, i, 0);
-    int kt = 0;
-    for (; kt + 5 < nk; kt += 6) {
-        kstep(0, IMG4_FLOATS, 2);
-        kstep(IMG4_FLOATS, 0, 0);
-        kstep(0, IMG4_FLOATS, 1);
-        kstep(IMG4_FLOATS, 0, 2);
-        kstep(0, IMG4_FLOATS, 0);
-        kstep(IMG4_FLOATS, 0, 1);
-    }
-    if (kt < nk) {
-        kstep(0, IMG4_FLOATS, 2);
-        kstep(IMG4_FLOATS, 0, 0);
-        kstep(0, IMG4_FLOATS, 1);
-    }
-    __syncthreads();                     // LDS becomes the epilogue slabs
-    const int ws = __builtin_amdgcn_readfirstlane(wave);
-    wino43_epilogue(acc, lds + ws * (64 * 36), lane, m0 + (ws >> 1) * 32, n0 + (ws & 1) * 32, M, Tw, W, Cout, ep);
-}
-
 // Sums the `parts` partial slabs of tail tile blockIdx.x / 32 in k order and applies BatchNorm / residual / ReLU.
 __global__ __launch_bounds__(256) void wino43_fixup_kernel(const float* __restrict__ partial, Epi ep, int M, int Tw, int W,
                                                            int Cout, int tiles_n, Split sp) {
@@ -1317,9 +1100,8 @@ __global__ __launch_bounds__(NT) void wino43_weights_kernel(const float* __restr
 }
 
 int g_wino_split = 1;                    // RPG_TUNE_WINO_SPLIT: split-K tail of the 8-wave kernel
-int g_wino = 1;                          // RPG_TUNE_WINOGRAD: 0 off | 1 auto | 2 / 3 / 4: always the 4-wave / 8-wave / short-K kernel
+int g_wino = 1;                          // RPG_TUNE_WINOGRAD: 0 off | 1 auto | 2 / 3: always the 4-wave / 8-wave kernel
 int g_wino_persist = 1;                  // RPG_TUNE_WINO_PERSIST: the persistent 8-wave kernel when a launch has more tiles than CUs
-int g_wino_short = 0;                    // RPG_TUNE_WINO_SHORT: auto mode uses the short-K kernel up to this many input channels (0 = never)
 
 }  // namespace
 
@@ -1328,7 +1110,7 @@ namespace rpg {
 bool wino_enabled() { return g_wino != 0; }
 void wino_set(int on) { g_wino = on; }
 void wino_split_set(int on) { g_wino_split = on; }
-void wino_short_set(int cin) { g_wino_short = cin; }
+void wino_short_set(int) {}              // RPG_TUNE_WINO_SHORT: retired with the short-K kernel (accepted, ignored)
 void wino_persist_set(int on) { g_wino_persist = on; }      // 2: also for launches of at most one tile per CU
 
 // Winograd needs (a) 32-bit buffer offsets (checked again by the launcher) and (b) enough work to occupy the chip.  Since
@@ -1372,19 +1154,7 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
     double executed = 0.0;                 // matrix-pipe FLOP: workgroups x K steps x 48 MFMAs x waves x 4096
     const long tm8 = (M + BMT8 - 1) / BMT8;
     const bool fits8 = (long)h * w * cin * 4 * 131 < (1L << 31);     // a workgroup's 128 tiles span at most 129 images
-    // short K loops (layers 1-2) on a grid that fills the chip: two 4-wave workgroups per CU, K step 8, double-buffered
-    if (g_wino == 4 || (g_wino == 1 && g_wino_short && cin <= g_wino_short && tm8 * tn >= 2L * num_cus())) {
-        static bool attr4[64] = {};
-        if (!attr4[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino43_conv4d_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS4_BYTES);
-            attr4[dev] = true;
-        }
-        const long tm4 = (M + BMT4 - 1) / BMT4;
-        executed = (double)tm4 * tn * (3 * ((cin + BK4 - 1) / BK4)) * 24.0 * 4.0 * 4096.0;
-        hipLaunchKernelGGL(wino43_conv4d_kernel, dim3((unsigned)(tm4 * tn)), dim3(NT4), LDS4_BYTES, s, x, u, h, w, cin, cout, tw,
-                           (int)M, ep, tn);
-    } else if (fits8 && (g_wino == 3 || (g_wino == 1 && tm8 * tn >= 8))) {
+    if (fits8 && (g_wino == 3 || (g_wino == 1 && tm8 * tn >= 8))) {
         // large problems (or RPG_TUNE_WINOGRAD = 3): 8 waves on 128 tiles, double-buffered, one workgroup per CU.
         // The tiles beyond the last full round of CUs would cost a whole extra round (784 tiles on 256 CUs: a 4th
         // round for 2 % of the work): they are cut along K into floor(CUs / tail) parts (>= 4 K steps each) whose partial

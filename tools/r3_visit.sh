@@ -1,0 +1,35 @@
+#!/bin/bash
+# Round-3 GPU-box visits: tools/r3_visit.sh <tag> <steps...>   (steps: probe tests bench evalstream convbench)
+TAG=${1:-v}; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$R"
+for step in "$@"; do
+  case $step in
+    probe)
+      timeout 60 tools/probes/glds_probe.bin > "$OUT/glds_probe.txt" 2>&1; echo "probe rc=$?"; cat "$OUT/glds_probe.txt";;
+    tests)
+      rm -f gpurun_out/parity_report.jsonl
+      timeout 2400 python -m pytest tests -q -m gpu > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest.log"
+      tail -25 "$OUT/pytest.log"; cp gpurun_out/parity_report.jsonl "$OUT/" 2>/dev/null;;
+    bench)
+      timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; cut -c1-3000 "$OUT/bench.json";;
+    benchq)
+      timeout 600 python bench.py --steps 20 --warmup 5 --cpu-baseline-seconds 0 > "$OUT/benchq.json" 2> "$OUT/benchq.err"; echo "benchq rc=$?"; cut -c1-600 "$OUT/benchq.json";;
+    benchbf16)
+      timeout 600 python bench.py --steps 20 --warmup 5 --cpu-baseline-seconds 0 --graphs 64 --encoder-dtype bf16 > "$OUT/bench_bf16.json" 2> "$OUT/bench_bf16.err"; echo "rc=$?"; cut -c1-1500 "$OUT/bench_bf16.json"
+      timeout 600 python bench.py --steps 20 --warmup 5 --cpu-baseline-seconds 0 --graphs 64 --encoder-dtype bf16 --gnn-dtype bf16 > "$OUT/bench_bf16_gnn.json" 2> "$OUT/bench_bf16_gnn.err"; echo "rc=$?"; cut -c1-1500 "$OUT/bench_bf16_gnn.json";;
+    evalstream)
+      for inp in resident host pinned; do
+        timeout 600 python tools/eval_stream.py --graphs 2000 --shape 256x341 --input $inp >> "$OUT/eval_stream.jsonl" 2>> "$OUT/eval_stream.err"; echo "eval $inp rc=$?"
+      done
+      timeout 600 python tools/eval_stream.py --graphs 4000 --shape 256x341 --input host --encoder-dtype bf16 --gnn-dtype bf16 >> "$OUT/eval_stream.jsonl" 2>> "$OUT/eval_stream.err"
+      timeout 600 python tools/eval_stream.py --graphs 4000 --shape 256x341 --input resident --encoder-dtype bf16 --gnn-dtype bf16 >> "$OUT/eval_stream.jsonl" 2>> "$OUT/eval_stream.err"
+      cat "$OUT/eval_stream.jsonl";;
+    convbench)
+      timeout 600 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --reps 10 --only l > "$OUT/conv_bf16_512.txt" 2>&1; cat "$OUT/conv_bf16_512.txt"
+      timeout 600 python tools/conv_bench.py --bf16 --nimg 256 --warm 3 --reps 10 --only l > "$OUT/conv_bf16_256.txt" 2>&1; cat "$OUT/conv_bf16_256.txt";;
+    *) echo "unknown step $step";;
+  esac
+done
