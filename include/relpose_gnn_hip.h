@@ -112,7 +112,19 @@ int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors, const int
  *   rpg_conv2d_bn_act_nhwc_bf16: x, w_ohwi, residual, y are bf16 (y is fp32 when out_f32 != 0); scale/shift fp32;
  *                                cin % 8 == 0, cout % 4 == 0; other arguments as rpg_conv2d_bn_act_nhwc_f32.
  *   rpg_resnet_forward_bf16:     tensors = per conv {w_ohwi bf16 (stem Cin padded 3 -> 8), scale f32, shift f32}, then
- *                                fc weight bf16 [feat][512], fc bias f32; x_nchw fp32 -> feat fp32 [n][feat_dim].      */
+ *                                fc weight bf16 [feat][512], fc bias f32, then OPTIONALLY the wpack of the fused bf16 stem
+ *                                below (64-channel stems; without it: re-layout + generic convolution + max-pool kernels);
+ *                                x_nchw fp32 -> feat fp32 [n][feat_dim].
+ *   rpg_stem_conv7x7s2_bn_relu_maxpool_bf16: the stem of the bf16 encoder in one kernel (same op chain and shapes as
+ *                                rpg_stem_conv7x7s2_bn_relu_maxpool_f32; torchvision conv1 / bn1 / relu / maxpool reached from
+ *                                posenet.py:1037): x_nchw fp32 [n][3][h][w] -> y bf16 [n][hp][wp][64]; inputs and weights
+ *                                rounded to bf16, fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 scale / shift / ReLU /
+ *                                max, one bf16 rounding at the store.
+ *                                wpack_bf16 [11][2][64][8] bf16: element [s][nf][l][j] = W[ch = 32 nf + (l & 31)][c][kh][kw = j]
+ *                                with (c, kh) = divmod(2 s + (l >> 5), 7); zero for j == 7 and for the 22nd (c, kh) row
+ *                                (relpose-gnn_amd/params.py pack_stem_bf16 builds it).                                   */
+int rpg_stem_conv7x7s2_bn_relu_maxpool_bf16(const float* x_nchw, const void* wpack_bf16, const float* scale, const float* shift,
+                                            void* y_nhwc_bf16, int n, int h, int w, void* stream);
 int rpg_conv2d_bn_act_nhwc_bf16(const void* x, const void* w_ohwi, const float* scale, const float* shift,
                                 const void* residual, void* y, int n, int h, int w, int cin, int cout, int kh, int kw,
                                 int stride, int pad, int relu, int out_f32, void* stream);
@@ -277,6 +289,8 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
                                      tiles, loads pipelined across tiles; needs Cin % 16 == 0) (default) | 2: also launches of at most one
                                      tile per CU (measured equal) | 0: one workgroup per tile */
 #define RPG_TUNE_BF16_TILE 15     /* tile of the interleaved bf16 convolution kernel: -1 by shape (default) | 0: 64x64 | 1: 128x128 | 2: 256x64 | 3: 128x64 */
+#define RPG_TUNE_BF16_DMA 16      /* the LDS-DMA bf16 convolution kernel (buffer_load ... lds, counted vmcnt, up to 256 x 256 tiles on 8 waves):
+                                     0: off | 1: by shape (default) | 10 + i: configuration i wherever eligible (experiments) */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -35,11 +35,18 @@ struct EpiB {
     const float* res2_f32 = nullptr;
     const int64_t* res2_idx = nullptr;
     int ldr = 0;
+    // optional SECOND output in bf16 (round 3: the next GEMM's A operand straight from this epilogue instead of a separate
+    // f32 -> bf16 pass): out2[m * ld2 + n] = bf16(relu2 ? max(y, 0) : y) of the same y (before the primary's own ReLU);
+    // `out` may then be null (bf16-only consumer)
+    __bf16* out2 = nullptr;
+    int ld2 = 0;
+    int relu2 = 0;
 };
 
 struct ConvArgsB {
     const __bf16* x;
     int H, W, Cin, KH, KW, stride, pad, Ho, Wo;
+    int img_elems = 0;         // elements between consecutive images; 0 = H * W * Cin (a Linear whose A rows have a pitch lda > k)
 };
 
 __device__ __forceinline__ uint4 ld16_or_zero(const __bf16* p, bool ok) {
@@ -50,11 +57,11 @@ __device__ __forceinline__ uint4 ld16_or_zero(const __bf16* p, bool ok) {
 
 // Epilogue shared by both kernels: each wave transposes its accumulators through a private fp32 LDS slab; each lane
 // finishes 4 consecutive channels of a row (BatchNorm scale/shift, bf16 residual, ReLU, bf16 or fp32 store).
-template <int FM, int FN, int SLAB_BUDGET_BYTES>
+template <int FM, int FN, int SLAB_BUDGET_BYTES, int NWAVES = 4>
 __device__ __forceinline__ void bf16_tile_epilogue(f32x16 (&acc)[FM][FN], unsigned char* lds_raw, const EpiB& ep, int m0,
                                                    int n0, int M, int N, int wm, int wn, int lane, int wave) {
     constexpr int EW = FN * 32, EPITCH = EW + 4, C4 = EW / 4, RPI = 64 / C4, NIT = 32 / RPI;
-    static_assert(4 * 32 * EPITCH * 4 <= SLAB_BUDGET_BYTES, "epilogue slab does not fit the staging LDS");
+    static_assert(NWAVES * 32 * EPITCH * 4 <= SLAB_BUDGET_BYTES, "epilogue slab does not fit the staging LDS");
     float* slab = reinterpret_cast<float*>(lds_raw) + wave * (32 * EPITCH);
     const int c4 = lane % C4, r_in = lane / C4;
     const int nb = n0 + wn * EW + 4 * c4;
@@ -108,8 +115,14 @@ __device__ __forceinline__ void bf16_tile_epilogue(f32x16 (&acc)[FM][FN], unsign
                         y.x += r2.x; y.y += r2.y; y.z += r2.z; y.w += r2.w;
                     }
                 }
+                if (ep.out2) {
+                    const float f2 = ep.relu2 ? 0.f : -INFINITY;
+                    const bf16x4 o2 = {(__bf16)fmaxf(y.x, f2), (__bf16)fmaxf(y.y, f2), (__bf16)fmaxf(y.z, f2), (__bf16)fmaxf(y.w, f2)};
+                    *reinterpret_cast<bf16x4*>(ep.out2 + (size_t)m * ep.ld2 + nb) = o2;
+                }
                 if (ep.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
-                if (ep.out_f32) {
+                if (!ep.out) {
+                } else if (ep.out_f32) {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(ep.out) + o) = y;
                 } else {
                     const bf16x4 ob = {(__bf16)y.x, (__bf16)y.y, (__bf16)y.z, (__bf16)y.w};
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(ConvArgsB a, const __bf16
         if (m < M) {
             const int wo = m % a.Wo;
             const int t = m / a.Wo;
-            img[j] = a.x + (size_t)(t / a.Ho) * a.H * a.W * a.Cin;
+            img[j] = a.x + (size_t)(t / a.Ho) * (a.img_elems ? a.img_elems : a.H * a.W * a.Cin);
             hi0[j] = (t % a.Ho) * a.stride - a.pad;
             wi0[j] = wo * a.stride - a.pad;
         } else {
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(NT) void conv_bf16_fast_kernel(ConvArgsB a, const _
 
     // ---- A rows: element offset of the row's image relative to the tile's first image, top-left input pixel
     const int n_first = m0 / (a.Ho * a.Wo);
-    const int img = a.H * a.W * a.Cin;
+    const int img = a.img_elems ? a.img_elems : a.H * a.W * a.Cin;
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x) + (size_t)n_first * img, 0,
                                                                           0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wt), 0, 0x7fffffff, 0x00020000);
@@ -426,6 +439,192 @@ __global__ __launch_bounds__(NT) void conv_bf16_fast_kernel(ConvArgsB a, const _
     bf16_tile_epilogue<FM, FN, 2 * STAGE * 2>(acc, lds_raw, ep, m0, n0, M, N, wm, wn, lane, wave);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The LDS-DMA kernel (round 3).  PMC of the interleaved kernel above on layer 3 showed 37 % MFMA-busy next to 40 % LDS-busy
+// and 43 % TA-busy with waves waiting on LDS a quarter of their cycles: every operand byte crossed the register file twice
+// (buffer_load -> VGPR -> ds_write_b128) and a 64 x 64 wave tile reads one LDS fragment per MFMA.  Here
+//   * global -> LDS goes by `buffer_load_dwordx4 ... lds` (LDS-DMA): no staging registers, no ds_write instructions; a wave
+//     instruction moves one 1-KB piece = 64 / CH rows of CH 16-byte chunks to M0 + 16 * lane (lane-linear destination), so
+//     the XOR swizzle that keeps ds_read_b128 conflict-free is applied to the SOURCE chunk each lane fetches;
+//   * out-of-image taps, ragged rows and the steps past K carry an out-of-range offset: the DMA writes zeros (probed:
+//     tools/probes/glds_probe.hip), so borders cost nothing and every step issues the same number of loads -- which is
+//     what makes a COUNTED s_waitcnt vmcnt((ST - 2) * pieces) possible: ST LDS images, loads run ST - 1 steps ahead of the
+//     MFMAs and are never drained inside the loop (raw s_barrier, not __syncthreads(), which would wait vmcnt(0));
+//   * 8 waves (two per SIMD) on tiles up to 256 x 256: a 128 x 64 wave tile reads 6 fragments per 8 MFMAs;
+//   * one barrier per K step: it publishes step t's pieces and retires image (t - 1) % ST, which the loads issued right
+//     behind it (step t + ST - 1) overwrite.
+// Requirements: Cin % BK == 0 (a K step never straddles a kernel tap), 32-bit offsets (checked by the launcher).
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+// (a plain function, not spelled inside the kernel template: the builtin does not exist for the host target, and an
+// instantiation that names it is silently dropped from the host side -- no launch stub, an undefined symbol at load time)
+__device__ __forceinline__ void dma_piece16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_dst, unsigned voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)lds_dst, 16, voffset, soffset, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int ST>
+__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a, const __bf16* __restrict__ Wt, int M, int N, int K,
+                                                                       EpiB ep, int tiles_n) {
+    constexpr int NW = WM * WN;
+    constexpr int CH = BK / 8, RPG = 64 / CH;                  // 16-byte chunks per row; rows per 1-KB piece
+    constexpr int NA = BM / RPG, NB = BN / RPG;                // pieces per image
+    static_assert(NA % NW == 0 && NB % NW == 0, "pieces must divide evenly over the waves");
+    static_assert(BK == 64 || BK == 32, "K step");
+    constexpr int JA = NA / NW, JB = NB / NW, NJ = JA + JB;    // pieces per wave and step
+    constexpr int FM = BM / WM / 32, FN = BN / WN / 32, KB = BK / 16, NR = FM + FN;
+    constexpr int IMG_B = (BM + BN) * BK * 2;                  // bytes per LDS image
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert((ST - 2) * NJ < 64, "vmcnt is 6 bits");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- DMA side.  Wave w moves A pieces w, w + NW, ... and B pieces w, w + NW, ...; lane l of a piece: row l / CH,
+    // physical chunk l % CH <- logical chunk (l % CH) ^ swz(row).  swz(row) = (row >> 1) & 7 (128-byte rows) or
+    // (row >> 2) & 3 (64-byte rows): the 16 rows of every ds_read_b128 lane group then sit on 16 distinct 16-byte slots of the
+    // 256-byte bank row.  Pieces start on multiples of RPG rows and NW is even, so the swizzle is the same for all of a lane's pieces.
+    const int r_in = lane / CH, pc = lane % CH;
+    const int swz_w = BK == 64 ? ((r_in >> 1) + 4 * (wave & 1)) & 7 : (r_in >> 2) & 3;
+    const int lc = pc ^ swz_w;
+    const int n_first = m0 / (a.Ho * a.Wo);
+    const int img = a.img_elems ? a.img_elems : a.H * a.W * a.Cin;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x) + (size_t)n_first * img, 0,
+                                                                          0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wt), 0, 0x7fffffff, 0x00020000);
+    int base[JA], hi0[JA], wi0[JA];
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+        const int m = m0 + (wave + NW * j) * RPG + r_in;
+        base[j] = -1; hi0[j] = 0; wi0[j] = 0;
+        if (m < M) {
+            const int wo = m % a.Wo;
+            const int t = m / a.Wo;
+            base[j] = (t / a.Ho - n_first) * img;
+            hi0[j] = (t % a.Ho) * a.stride - a.pad;
+            wi0[j] = wo * a.stride - a.pad;
+        }
+    }
+    unsigned voff[JA], woff[JB], weff[JB];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+        const int n = n0 + (wave + NW * j) * RPG + r_in;
+        woff[j] = n < N ? 2u * (unsigned)(n * K + 8 * lc) : OOB;
+    }
+    int kh = 0, kw = 0, c0 = 0, k0 = 0;                   // wave-uniform position of the next fetch (K % BK == 0)
+    auto refresh = [&]() {                                // offsets of tap (kh, kw); everything out of range past K
+        asm volatile("");                                 // keeps the callers' branch
+        const bool live = k0 < K;
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+            const bool ok = live && base[j] >= 0 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            voff[j] = ok ? 2u * (unsigned)(base[j] + (hi * a.W + wi) * a.Cin + 8 * lc) : OOB;
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) weff[j] = live ? woff[j] : OOB;
+    };
+    refresh();
+    auto issue_step = [&](int im) {                       // all pieces of the next K step -> image im (compile-time index)
+#pragma unroll
+        for (int j = 0; j < JA; ++j)
+            dma_piece16(rsa, lds_raw + im * IMG_B + (wave + NW * j) * 1024, voff[j], 2 * c0);
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+            dma_piece16(rsw, lds_raw + im * IMG_B + BM * BK * 2 + (wave + NW * j) * 1024, weff[j], 2 * k0);
+        k0 += BK;
+        c0 += BK;
+        if (c0 >= a.Cin || k0 >= K) {
+            if (c0 >= a.Cin) { c0 = 0; if (++kw == a.KW) { kw = 0; ++kh; } }
+            refresh();
+        }
+    };
+
+    // ---- MFMA side: fragment of lane (row = lane & 31, k half = lane >> 5) for the 16-wide k group g = logical chunk 2g + half
+    const int lrow = lane & 31, half = lane >> 5;
+    const int sw = BK == 64 ? (lrow >> 1) & 7 : (lrow >> 2) & 3;
+    unsigned cbyte[KB];                                    // byte offset of (row lrow, chunk of group g) inside a 32-row block
+#pragma unroll
+    for (int g = 0; g < KB; ++g) cbyte[g] = (unsigned)(lrow * BK * 2 + 16 * ((2 * g + half) ^ sw));
+    const int a_blk = wm * FM * 32 * BK * 2, b_blk = (BM + wn * FN * 32) * BK * 2;       // wave-uniform byte offsets
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto compute = [&](int im) {                           // one K step on image im (compile-time index)
+        const unsigned char* L = lds_raw + im * IMG_B;
+        bf16x8 fr[2][NR];
+        auto read_group = [&](int set, int g) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                fr[set][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(L + a_blk + i * 32 * BK * 2 + cbyte[g]));
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                fr[set][FM + j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(L + b_blk + j * 32 * BK * 2 + cbyte[g]));
+        };
+        read_group(0, 0);
+#pragma unroll
+        for (int g = 0; g < KB; ++g) {
+            if (g + 1 < KB) read_group((g + 1) & 1, g + 1);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g & 1][i], fr[g & 1][FM + j], acc[i][j], 0, 0, 0);
+            // the next group's operand reads go one at a time behind this group's MFMAs (left alone, hipcc serialises
+            // read - wait - MFMA with a single fragment set): MFMA, ds_read, MFMA, ds_read, ...
+            if (g + 1 < KB) {
+#pragma unroll
+                for (int u = 0; u < FM * FN; ++u) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA
+                    if (u < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // one ds_read
+                }
+            }
+        }
+    };
+
+    const int nk = K / BK;
+    // prologue: steps 0 .. ST-2 in flight (steps past the end are all out of range: zero pieces, same instruction count)
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s) issue_step(s);
+    // step t: its pieces have landed when at most (ST - 2) * NJ younger loads of this wave are outstanding; the barrier makes
+    // that true for every wave's pieces and retires image (t - 1) % ST = (t + ST - 1) % ST, the target of the loads issued next
+#define RPG_DMA_STEP(IMX)                                                              \
+    do {                                                                               \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * NJ) : "memory");           \
+        __builtin_amdgcn_s_barrier();                                                  \
+        asm volatile("" ::: "memory");   /* no LDS read of this step above the barrier */ \
+        issue_step((IMX + ST - 1) % ST);                                               \
+        compute(IMX);                                                                  \
+    } while (0)
+    int t = 0;
+    for (; t + ST <= nk; t += ST) {
+        RPG_DMA_STEP(0);
+        RPG_DMA_STEP(1);
+        if (ST > 2) RPG_DMA_STEP(2 % ST);
+        if (ST > 3) RPG_DMA_STEP(3 % ST);
+    }
+    if (t < nk) { RPG_DMA_STEP(0); ++t; }
+    if (t < nk) { RPG_DMA_STEP(1); ++t; }
+    if (ST > 3 && t < nk) { RPG_DMA_STEP(2 % ST); ++t; }
+#undef RPG_DMA_STEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the zero pieces of the steps past K: LDS becomes the epilogue slabs
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bf16_tile_epilogue<FM, FN, ST * IMG_B, NW>(acc, lds_raw, ep, m0, n0, M, N, wm, wn, lane, wave);
+}
+
+int g_bf16_fused_stem = 1;   // RPG_TUNE_FUSED_STEM also selects the bf16 encoder's fused stem (stem_bf16.hip)
+int g_bf16_dma = 1;      // RPG_TUNE_BF16_DMA: 0 off | 1 by shape | 10 + i: configuration i of launch_dma_config wherever it is eligible
 int g_bf16_tile = -1;    // RPG_TUNE_BF16_TILE: -1 auto | 0: 64x64 | 1: 128x128 | 2: 256x64 | 3: 128x64 (interleaved kernel only)
 int g_bf16_fast = 1;     // RPG_TUNE_BF16_FAST: the interleaved buffer-load kernel where eligible
 int g_bf16_bk = 32;      // measured on MI355X at 64 graphs: K step 32 -> 9.97 ms/step, 64 -> 12.5 (the 72-KB LDS image halves occupancy)
@@ -458,6 +657,41 @@ void launch_fast(const ConvArgsB& a, const __bf16* w, int M, int N, int K, const
     }
     const int tn = (N + BN - 1) / BN, tm = (M + BM - 1) / BM;
     hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(NT), lds, s, a, w, M, N, K, ep, tn);
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int ST>
+void launch_dma(const ConvArgsB& a, const __bf16* w, int M, int N, int K, const EpiB& ep, hipStream_t s) {
+    constexpr int lds = ST * (BM + BN) * BK * 2;
+    static_assert(lds <= 160 * 1024, "LDS images do not fit a CU");
+    auto kern = conv_bf16_dma_kernel<BM, BN, WM, WN, BK, ST>;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    static bool once[64] = {};
+    if (!once[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        once[dev] = true;
+    }
+    const int tn = (N + BN - 1) / BN, tm = (M + BM - 1) / BM;
+    hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(64 * WM * WN), lds, s, a, w, M, N, K, ep, tn);
+}
+
+// configuration table of the LDS-DMA kernel (index = RPG_TUNE_BF16_DMA - 10); returns false if the index is unknown or the
+// shape is not eligible for it (Cin % BK)
+bool launch_dma_config(int cfg, const ConvArgsB& a, const __bf16* w, int M, int N, int K, const EpiB& ep, hipStream_t s) {
+    const bool k64 = a.Cin % 64 == 0, k32 = a.Cin % 32 == 0;
+    switch (cfg) {
+        case 0: if (!k64) return false; launch_dma<256, 256, 2, 4, 64, 2>(a, w, M, N, K, ep, s); return true;   // 128 KB, wave 128 x 64
+        case 1: if (!k64) return false; launch_dma<256, 128, 4, 2, 64, 3>(a, w, M, N, K, ep, s); return true;   // 144 KB, wave 64 x 64
+        case 2: if (!k64) return false; launch_dma<256, 128, 2, 2, 64, 3>(a, w, M, N, K, ep, s); return true;   // 4 waves, wave 128 x 64
+        case 3: if (!k64) return false; launch_dma<128, 128, 2, 2, 64, 2>(a, w, M, N, K, ep, s); return true;   // 64 KB: 2 workgroups / CU
+        case 4: if (!k64) return false; launch_dma<256, 64, 4, 2, 64, 3>(a, w, M, N, K, ep, s); return true;    // 120 KB, wave 64 x 32
+        case 5: if (!k64) return false; launch_dma<256, 64, 4, 2, 64, 2>(a, w, M, N, K, ep, s); return true;    // 80 KB: 2 workgroups / CU
+        case 6: if (!k32) return false; launch_dma<256, 256, 2, 4, 32, 4>(a, w, M, N, K, ep, s); return true;   // 128 KB, 3 steps ahead
+        case 7: if (!k32) return false; launch_dma<256, 128, 4, 2, 32, 3>(a, w, M, N, K, ep, s); return true;   // 72 KB: 2 workgroups / CU
+        case 8: if (!k64) return false; launch_dma<128, 128, 2, 2, 64, 3>(a, w, M, N, K, ep, s); return true;   // 96 KB
+        case 9: if (!k32) return false; launch_dma<128, 64, 2, 2, 32, 4>(a, w, M, N, K, ep, s); return true;    // 48 KB: 3 workgroups / CU
+        default: return false;
+    }
 }
 
 // ---- streaming kernels on bf16 NHWC tensors (8 elements = 16 bytes per lane) ----
@@ -542,6 +776,8 @@ namespace rpg {
 void bf16_set_bk(int bk) { g_bf16_bk = bk; }
 void bf16_set_fast(int on) { g_bf16_fast = on; }
 void bf16_set_tile(int t) { g_bf16_tile = t; }
+void bf16_set_dma(int v) { g_bf16_dma = v; }
+void bf16_set_fused_stem(int on) { g_bf16_fused_stem = on; }
 
 // fp32 [rows][ld_src] (first `cols` columns) -> bf16 dst[rows][ld_dst] at column offset col_off (cols % 8 == 0)
 __global__ __launch_bounds__(NT) void f32_to_bf16_kernel(const float* __restrict__ src, int ld_src, __bf16* __restrict__ dst,
@@ -572,16 +808,30 @@ int launch_f32_to_bf16(const float* src, int ld_src, void* dst, int ld_dst, int 
 int launch_linear_bf16(const void* a, const void* w, const float* bias, const float* res, const int64_t* res_idx,
                        const float* res2, const int64_t* res2_idx, int ldr, float* out, int m, int k, int n_out, int relu,
                        hipStream_t s) {
-    if (!a || !w || !out || m <= 0 || k <= 0 || n_out <= 0 || (k & 7) || (n_out & 3) || !aligned16(a) || !aligned16(w) ||
-        !aligned16(out) || (bias && !aligned16(bias)) || (res && (!aligned16(res) || (ldr & 3) || ldr < n_out)) ||
-        (res2 && (!res || !res2_idx || !aligned16(res2))))
+    LinearBf16Out o{};
+    o.out = out; o.out_f32 = 1;
+    return launch_linear_bf16_ex(a, k, w, bias, res, res_idx, res2, res2_idx, ldr, o, m, k, n_out, relu, s);
+}
+
+// The general form: A rows with pitch lda >= k (a column block of a wider bf16 matrix), primary output fp32 or bf16 or
+// none, optional second bf16 output with its own pitch and ReLU (EpiB::out2): the Linears of the bf16 GNN hand their result
+// to the next GEMM in bf16 from the epilogue.
+int launch_linear_bf16_ex(const void* a, int lda, const void* w, const float* bias, const float* res, const int64_t* res_idx,
+                          const float* res2, const int64_t* res2_idx, int ldr, const LinearBf16Out& o, int m, int k, int n_out,
+                          int relu, hipStream_t s) {
+    if (!a || !w || (!o.out && !o.out2) || m <= 0 || k <= 0 || n_out <= 0 || (k & 7) || (n_out & 3) || lda < k || (lda & 7) ||
+        !aligned16(a) || !aligned16(w) || (o.out && !aligned16(o.out)) || (bias && !aligned16(bias)) ||
+        (res && (!aligned16(res) || (ldr & 3) || ldr < n_out)) || (res2 && (!res || !res2_idx || !aligned16(res2))) ||
+        (o.out2 && ((reinterpret_cast<uintptr_t>(o.out2) & 7) || (o.ld2 & 3) || o.ld2 < n_out)))
         return RPG_ERR_BAD_ARG;
     ConvArgsB ca{reinterpret_cast<const __bf16*>(a), 1, 1, k, 1, 1, 1, 0, 1, 1};
-    EpiB ep{nullptr, bias, nullptr, out, n_out, relu, 1};
+    ca.img_elems = lda == k ? 0 : lda;
+    EpiB ep{nullptr, bias, nullptr, o.out, n_out, relu, o.out_f32};
     ep.res_f32 = res; ep.res_idx = res_idx; ep.res2_f32 = res2; ep.res2_idx = res2_idx; ep.ldr = ldr;
+    ep.out2 = reinterpret_cast<__bf16*>(o.out2); ep.ld2 = o.ld2; ep.relu2 = o.relu2;
     const __bf16* wp = reinterpret_cast<const __bf16*>(w);
     const int slot = timing_begin(RPG_TIMER_LINEAR, s);
-    const bool fast = g_bf16_fast && k % 64 == 0 && 258L * k * 2 < (1L << 31) && (long)n_out * k * 2 < (1L << 31);
+    const bool fast = g_bf16_fast && k % 64 == 0 && 258L * lda * 2 < (1L << 31) && (long)n_out * k * 2 < (1L << 31);
     const long t128 = (long)((m + 127) / 128) * ((n_out + 127) / 128);
     if (fast) {
         if (t128 >= 192) launch_fast<128, 128, 2, 2>(ca, wp, m, n_out, k, ep, s);
@@ -615,7 +865,10 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
     // first image of a tile (whose <= 256 rows span at most 256 / (ho*wo) + 2 images)
     const long span = 256 / ((long)ho * wo) + 2;
     const bool fast = g_bf16_fast && cin % 64 == 0 && span * h * wd * cin * 2 < (1L << 31) && (long)cout * K * 2 < (1L << 31);
-    if (fast && g_bf16_tile >= 0) {       // RPG_TUNE_BF16_TILE: forced tile of the interleaved kernel (experiments)
+    const bool dma_ok = span * h * wd * cin * 2 < (1L << 31) && (long)cout * K * 2 < (1L << 31);
+    if (dma_ok && g_bf16_dma >= 10 && launch_dma_config(g_bf16_dma - 10, a, wp, (int)M, cout, (int)K, ep, s)) {
+        // forced configuration (experiments)
+    } else if (fast && g_bf16_tile >= 0) {       // RPG_TUNE_BF16_TILE: forced tile of the interleaved kernel (experiments)
         if (g_bf16_tile == 0) launch_fast<64, 64, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);
         else if (g_bf16_tile == 1) launch_fast<128, 128, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);
         else if (g_bf16_tile == 3) launch_fast<128, 64, 4, 1>(a, wp, (int)M, cout, (int)K, ep, s);
@@ -678,7 +931,9 @@ extern "C" int rpg_resnet_forward_bf16(const void* const* tensors, int n_tensors
             cin = planes[l];
         }
     }
-    if (n_tensors != expect) return RPG_ERR_BAD_ARG;
+    // optional last tensor: the operands of the fused stem kernel (stem_bf16.hip; 64-channel stems)
+    if (n_tensors != expect && n_tensors != expect + 1) return RPG_ERR_BAD_ARG;
+    const void* stem_pack = n_tensors == expect + 1 ? tensors[expect] : nullptr;
     for (int i = 0; i < n_tensors; ++i)
         if (!tensors[i]) return RPG_ERR_BAD_ARG;
     if (workspace_bytes < rpg_resnet_bf16_workspace_bytes(n, h, w, planes)) return RPG_ERR_WORKSPACE;
@@ -706,20 +961,25 @@ extern "C" int rpg_resnet_forward_bf16(const void* const* tensors, int n_tensors
     for (int i = 0; i < 4; ++i) buf[i] = take(blk * 2);
     void* pool = take((size_t)n * planes[3] * 2);
 
-    const long npix = (long)n * h * w;
-    hipLaunchKernelGGL(nchw3_to_nhwc8_bf16_kernel, dim3(capped_grid(npix)), dim3(NT), 0, s, x_nchw,
-                       reinterpret_cast<uint4*>(in8), npix, h * w);
     int rc, ti = 0;
-    if ((rc = rpg::launch_conv_bf16(in8, tensors[0], (const float*)tensors[1], (const float*)tensors[2], nullptr, stem, n, h,
-                                    w, 8, planes[0], 7, 7, 2, 3, 1, 0, s)) != RPG_OK)
-        return rc;
-    ti += 3;
-    {
+    if (stem_pack && g_bf16_fused_stem && rpg::stem_pool_bf16_supported(h, w, planes[0])) {
+        // fp32 NCHW -> conv7x7/2 + BN + ReLU + maxpool3x3/2 -> pooled bf16 NHWC, one kernel
+        if ((rc = rpg::launch_stem_pool_bf16(x_nchw, stem_pack, (const float*)tensors[1], (const float*)tensors[2], buf[0], n, h, w,
+                                             s)) != RPG_OK)
+            return rc;
+    } else {
+        const long npix = (long)n * h * w;
+        hipLaunchKernelGGL(nchw3_to_nhwc8_bf16_kernel, dim3(capped_grid(npix)), dim3(NT), 0, s, x_nchw,
+                           reinterpret_cast<uint4*>(in8), npix, h * w);
+        if ((rc = rpg::launch_conv_bf16(in8, tensors[0], (const float*)tensors[1], (const float*)tensors[2], nullptr, stem, n, h,
+                                        w, 8, planes[0], 7, 7, 2, 3, 1, 0, s)) != RPG_OK)
+            return rc;
         const int c8 = planes[0] / 8;
         const long total = (long)n * h2 * w2 * c8;
         hipLaunchKernelGGL(maxpool3x3s2_bf16_kernel, dim3(capped_grid(total)), dim3(NT), 0, s,
                            reinterpret_cast<const uint4*>(stem), reinterpret_cast<uint4*>(buf[0]), h1, w1, c8, h2, w2, total);
     }
+    ti += 3;
     int cur = 0, hh = h2, ww = w2;
     cin = planes[0];
     for (int l = 0; l < 4; ++l) {

@@ -307,6 +307,70 @@ int gnn_forward_impl(const float* const* tensors, int n_tensors, const void* con
         return rpg::launch_linear(g, tensors[wt], tensors[bias_t], nullptr, out, e, d, 1, s, &gr);
     };
 
+    const bool fuse_agg = rpg::gnn_fuse_agg_enabled();
+    if (wb && fuse_agg && split) {
+        // ---- bf16 Linears, round 3: every GEMM hands its result to the next GEMM in bf16 FROM ITS EPILOGUE (EpiB::out2 /
+        // a bf16 primary output); the 21 separate f32 -> bf16 passes and the 2 in-place ReLU passes per forward of round 2
+        // are down to 4 conversions (encoder features, proj_edge output, 2 x the n x D/8 attention vector).  The bf16
+        // tensors live in the fp32 buffers this mode does not use (raw edge update, hidden, node hidden, agg).
+        typedef unsigned short bf;
+        bf* eb = reinterpret_cast<bf*>(eraw);                 // [e][d]   current edge features (A of edge_mlp.0's edge block)
+        bf* enb = eb + (size_t)e * d;                         // [e][d]   raw edge update (A of mlp.0's edge block)
+        bf* hb = reinterpret_cast<bf*>(hid);                  // [e][d]   hidden activations of edge_mlp / mlp
+        bf* mb = hb + (size_t)e * d;                          // [e][d]   messages (A of g|theta|phi)
+        bf* xab = reinterpret_cast<bf*>(nhid);                // [n][2d]  x | aggregated messages (A of mlp_updating.0; x alone: lda = 2d)
+        bf* nhb = reinterpret_cast<bf*>(agg);                 // [n][d]   hidden activations of mlp_updating
+        bf* yb = reinterpret_cast<bf*>(abf);                  // [n][c]   attention vector
+        auto gemm = [&](const void* a, int lda, int k, int bw, const float* bias, const float* r1, const int64_t* i1, const float* r2,
+                        const int64_t* i2, int ldr, void* out, int out_f32, void* out2, int ld2, int relu2, int m, int n_out, int relu) {
+            rpg::LinearBf16Out o{};
+            o.out = out; o.out_f32 = out_f32; o.out2 = out2; o.ld2 = ld2; o.relu2 = relu2;
+            return rpg::launch_linear_bf16_ex(a, lda, wb[bw], bias, r1, i1, r2, i2, ldr, o, m, k, n_out, relu, s);
+        };
+        if ((rc = rpg::launch_f32_to_bf16(feat, d, xab, 2 * d, 0, n, d, s)) != RPG_OK) return rc;
+        // edge_feat = relu(proj_edge(cat[x[min], x[max]]))                               posenet.py:1053-1055
+        if ((rc = gemm(xab, 2 * d, d, B_PROJN, nullptr, nullptr, nullptr, nullptr, nullptr, 0, node3, 1, nullptr, 0, 0, n, 2 * d, 0)) != RPG_OK) return rc;
+        float* ecur = ebuf[0];
+        if ((rc = rpg::launch_gather_add2_relu(node3, lo, hi, tensors[T_PROJ_B], ecur, e, d, s)) != RPG_OK) return rc;
+        if ((rc = rpg::launch_f32_to_bf16(ecur, d, eb, d, 0, e, d, s)) != RPG_OK) return rc;
+        const float* x = feat;
+        for (int r = 0; r < gnn_recursion; ++r) {                                       // posenet.py:1061-1069
+            const bool last = r + 1 == gnn_recursion;
+            float* xnew = xbuf[r & 1];
+            // edge update                                                              my_gnn_layer.py:296-297
+            if ((rc = gemm(xab, 2 * d, d, B_NODE3, nullptr, nullptr, nullptr, nullptr, nullptr, 0, node3, 1, nullptr, 0, 0, n, 3 * d, 0)) != RPG_OK) return rc;
+            if ((rc = gemm(eb, d, d, B_EDGE0E, tensors[T_EDGE0_B], node3, src, node3 + d, dst, 3 * d, hb, 0, nullptr, 0, 0, e, d, 1)) != RPG_OK) return rc;
+            // raw update -> enb (consumed by the message MLP); relu(update) (posenet.py:1065) -> the next recursion's bf16 edge
+            // features, or on the last recursion the fp32 ones the heads read
+            if (last) rc = gemm(hb, d, d, B_EDGE2, tensors[T_EDGE2_B], nullptr, nullptr, nullptr, nullptr, 0, ebuf[1], 1, enb, d, 0, e, d, 1);
+            else rc = gemm(hb, d, d, B_EDGE2, tensors[T_EDGE2_B], nullptr, nullptr, nullptr, nullptr, 0, eb, 0, enb, d, 0, e, d, 1);
+            if (rc != RPG_OK) return rc;
+            if (last) ecur = ebuf[1];
+            // message MLP, attention, aggregation                                      my_gnn_layer.py:301,304-307
+            if ((rc = gemm(enb, d, d, B_MSG0E, tensors[T_MSG0_B], node3 + 2 * d, src, nullptr, nullptr, 3 * d, hb, 0, nullptr, 0, 0, e, d, 1)) != RPG_OK) return rc;
+            if ((rc = gemm(hb, d, d, B_MSG2, tensors[T_MSG2_B], nullptr, nullptr, nullptr, nullptr, 0, msg, 1, mb, d, 0, e, d, 0)) != RPG_OK) return rc;
+            if ((rc = gemm(mb, d, d, B_GTP, tensors[T_GTP_B], nullptr, nullptr, nullptr, nullptr, 0, gtp, 1, nullptr, 0, 0, e, 3 * c, 0)) != RPG_OK) return rc;
+            if ((rc = rpg_attention_aggregate_f32(gtp, msg, rowptr, perm, tensors[T_ATTW_B], n, e, c, d, yat, att, stream)) != RPG_OK) return rc;
+            if ((rc = rpg::launch_f32_to_bf16(yat, c, yb, c, 0, n, c, s)) != RPG_OK) return rc;
+            // att.W on node rows; the aggregate goes straight to the right half of mlp_updating.0's bf16 input
+            if ((rc = gemm(yb, c, c, B_ATTW, nullptr, att, nullptr, nullptr, nullptr, d, nullptr, 0, xab + d, 2 * d, 0, n, d, 0)) != RPG_OK) return rc;
+            // node update                                                              my_gnn_layer.py:309-311
+            if ((rc = gemm(xab, 2 * d, 2 * d, B_UPD0, tensors[T_UPD0_B], nullptr, nullptr, nullptr, nullptr, 0, nhb, 0, nullptr, 0, 0, n, d, 1)) != RPG_OK) return rc;
+            if ((rc = gemm(nhb, d, d, B_UPD2, tensors[T_UPD2_B], nullptr, nullptr, nullptr, nullptr, 0, xnew, 1, xab, 2 * d, 1, n, d, 1)) != RPG_OK) return rc;
+            x = xnew;
+        }
+        if (node_out && hipMemcpyAsync(node_out, x, (size_t)n * d * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            rpg::set_last_error("gnn_forward node_out", hipGetLastError());
+            return RPG_ERR_LAUNCH;
+        }
+        if (edge_out && hipMemcpyAsync(edge_out, ecur, (size_t)e * d * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            rpg::set_last_error("gnn_forward edge_out", hipGetLastError());
+            return RPG_ERR_LAUNCH;
+        }
+        if ((rc = rpg_pose_heads_f32(x, tensors[T_HEADN_W], tensors[T_HEADN_B], n, d, abs_pose, stream)) != RPG_OK) return rc;
+        return rpg_pose_heads_f32(ecur, tensors[T_HEADE_W], tensors[T_HEADE_B], e, d, rel_pose, stream);
+    }
+
     // edge_feat = relu(proj_edge(cat[x[min], x[max]]))                                   posenet.py:1053-1055
     const float* x = feat;
     float* ecur = ebuf[0];
@@ -317,7 +381,6 @@ int gnn_forward_impl(const float* const* tensors, int n_tensors, const void* con
         return rc;
     }
 
-    const bool fuse_agg = rpg::gnn_fuse_agg_enabled();
     const bool dual = !wb;                 // fp32: the edge update is stored twice, raw (for the message) and rectified
     for (int r = 0; r < gnn_recursion; ++r) {                                           // posenet.py:1061-1069
         float* enext = (ecur == ebuf[0]) ? ebuf[1] : ebuf[0];    // relu(edge update): the next recursion's / the heads' input

@@ -78,10 +78,25 @@ void wino_short_set(int cin);
 void wino_persist_set(int on);
 void bf16_set_fast(int on);
 void bf16_set_tile(int t);
+void bf16_set_dma(int v);
+void bf16_set_fused_stem(int on);
+bool stem_pool_bf16_supported(int h, int w, int cout);
+int launch_stem_pool_bf16(const float* x_nchw, const void* wpack, const float* scale, const float* shift, void* out, int n, int h,
+                          int w, hipStream_t s);
 int launch_f32_to_bf16(const float* src, int ld_src, void* dst, int ld_dst, int col_off, long rows, int cols, hipStream_t s);
 int launch_linear_bf16(const void* a, const void* w, const float* bias, const float* res, const int64_t* res_idx,
                        const float* res2, const int64_t* res2_idx, int ldr, float* out, int m, int k, int n_out, int relu,
                        hipStream_t s);
+struct LinearBf16Out {
+    void* out = nullptr;       // primary output [m][n_out]: fp32 (out_f32) or bf16; may be null when out2 is given
+    int out_f32 = 1;
+    void* out2 = nullptr;      // optional second output, bf16, pitch ld2 elements: bf16(relu2 ? max(y, 0) : y), y = before the primary's ReLU
+    int ld2 = 0;
+    int relu2 = 0;
+};
+int launch_linear_bf16_ex(const void* a, int lda, const void* w, const float* bias, const float* res, const int64_t* res_idx,
+                          const float* res2, const int64_t* res2_idx, int ldr, const LinearBf16Out& o, int m, int k, int n_out,
+                          int relu, hipStream_t s);
 // Gathered residual rows added in the epilogue: out[m] += res1[idx1[m]] (+ res2[idx2[m]]), row pitch ld.
 struct GatherRes {
     const float* res1;

@@ -95,6 +95,11 @@ class _InputPipeline:
         self.device = device
         self.copy_stream = torch.cuda.Stream(device=device)
         self.host = [torch.empty((rows, row_floats), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        self.host_np = [t.numpy() for t in self.host]
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        self.workers = max(1, min(8, (os.cpu_count() or 2) // 2))
+        self.pool = ThreadPoolExecutor(max_workers=self.workers) if self.workers > 1 else None
         self.dev = [torch.empty((rows, row_floats), dtype=torch.float32, device=device) for _ in range(2)]
         self.sent = [torch.cuda.Event() for _ in range(2)]
         self.used = [torch.cuda.Event() for _ in range(2)]
@@ -109,13 +114,29 @@ class _InputPipeline:
             self.sent[k].synchronize()                 # the previous copy out of pinned buffer k has left the host
         host, dev, off = self.host[k], self.dev[k], 0
         direct = []                                    # graphs whose x is already pinned: copied from where they are
+        jobs = []
         for g in chunk:
             n = g.x.shape[0]
             if g.x.is_pinned():
                 direct.append((off, n, g.x))
             else:
-                host[off:off + n].copy_(g.x)
+                jobs.append((off, n, g.x))
             off += n
+        if jobs:
+            # pageable -> pinned by a few worker threads (numpy releases the GIL; one memcpy stream moves ~5 GB/s on the GPU
+            # host, measured r3: 649 graphs/s single-threaded against 1808 with resident images at 256x341)
+            host_np = self.host_np[k]
+
+            def copy_some(part):
+                for o, n, src in part:
+                    np.copyto(host_np[o:o + n], src.detach().numpy())
+            w = min(len(jobs), self.workers)
+            if w <= 1:
+                copy_some(jobs)
+            else:
+                futs = [self.pool.submit(copy_some, jobs[i::w]) for i in range(w)]
+                for f in futs:
+                    f.result()
         with torch.cuda.stream(self.copy_stream):
             if self.n_sent[k]:
                 self.copy_stream.wait_event(self.used[k])      # the forward that read device buffer k has finished

@@ -157,6 +157,21 @@ def stem_conv_bn_relu_maxpool(x_nchw: torch.Tensor, wpack: torch.Tensor, shift: 
     return y
 
 
+def stem_conv_bn_relu_maxpool_bf16(x_nchw: torch.Tensor, wpack_bf16: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+    """The bf16 encoder's stem in one kernel: fp32 [N,3,H,W] -> bf16 [N,Hp,Wp,64] (wpack_bf16 from params.pack_stem_bf16)."""
+    x_nchw, scale, shift = _req(x_nchw, "x_nchw"), _req(scale, "scale"), _req(shift, "shift")
+    wpack_bf16 = _req(wpack_bf16, "wpack_bf16", torch.bfloat16)
+    n, c, h, w = x_nchw.shape
+    if c != 3 or tuple(wpack_bf16.shape) != (11, 2, 64, 8) or scale.numel() != 64 or shift.numel() != 64:
+        raise ValueError("expected x [N,3,H,W], wpack_bf16 [11,2,64,8], scale / shift [64]")
+    hc, wc = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    hp, wp = (hc - 1) // 2 + 1, (wc - 1) // 2 + 1
+    y = torch.empty((n, hp, wp, 64), dtype=torch.bfloat16, device=x_nchw.device)
+    L.check(L.lib().rpg_stem_conv7x7s2_bn_relu_maxpool_bf16(_p(x_nchw), _p(wpack_bf16), _p(scale), _p(shift), _p(y), n, h, w,
+                                                           _stream()), "stem_conv_bn_relu_maxpool_bf16")
+    return y
+
+
 def maxpool3x3s2_nhwc(x: torch.Tensor) -> torch.Tensor:
     x = _req(x, "x")
     n, h, w, c = x.shape
@@ -296,7 +311,7 @@ def release_scratch() -> None:
     L.check(L.lib().rpg_release_scratch(), "release_scratch")
 
 
-TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST, TUNE_FUSED_STEM, TUNE_WAVES8, TUNE_WINO_SHORT, TUNE_GNN_FUSE_AGG, TUNE_WINO_PERSIST, TUNE_BF16_TILE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
+TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST, TUNE_FUSED_STEM, TUNE_WAVES8, TUNE_WINO_SHORT, TUNE_GNN_FUSE_AGG, TUNE_WINO_PERSIST, TUNE_BF16_TILE, TUNE_BF16_DMA = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16
 
 
 def set_tuning(key: int, value: int) -> None:

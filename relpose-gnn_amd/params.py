@@ -127,6 +127,19 @@ def pack_resnet(sd: Dict[str, torch.Tensor], prefix: str = "feature_extractor.",
     return t, blocks, planes
 
 
+def pack_stem_bf16(w_oihw: torch.Tensor) -> torch.Tensor:
+    """conv1.weight [64][3][7][7] -> wpack [11][2][64][8] bf16 of rpg_stem_conv7x7s2_bn_relu_maxpool_bf16: MFMA step s covers the
+    (channel, kernel row) pairs 2s (lanes 0-31) and 2s + 1 (lanes 32-63), 8 kernel columns each (the 8th, and the 22nd pair, are
+    zero); lane l of fragment nf holds output channel 32 nf + (l & 31).  Plain bf16 rounding (round-to-nearest-even), no scale
+    folded in: like every other bf16 convolution the BatchNorm affine is applied in fp32 to the accumulators."""
+    if tuple(w_oihw.shape) != (64, 3, 7, 7):
+        raise ValueError("the fused stem kernel is for Conv2d(3, 64, 7)")
+    w = w_oihw.float().reshape(64, 21, 7)                                    # [ch][(c, kh)][kw]
+    w = torch.nn.functional.pad(w, (0, 1, 0, 1))                             # [ch][22][8]: zero 8th column, zero 22nd row
+    w = w.view(2, 32, 11, 2, 8)                                              # [nf][n][s][h][j]
+    return w.permute(2, 0, 3, 1, 4).reshape(11, 2, 64, 8).to(torch.bfloat16).contiguous()     # [s][nf][l = 32 h + n][j]
+
+
 def pack_resnet_bf16(sd: Dict[str, torch.Tensor], prefix: str = "feature_extractor.") -> Tuple[List[torch.Tensor], List[int], List[int]]:
     """bf16 encoder (``rpg_resnet_forward_bf16``): per conv {w_ohwi bf16 (stem Cin padded to 8), scale f32, shift f32},
     then fc weight bf16, fc bias f32.  Weights are rounded to bf16 once (round-to-nearest-even)."""
@@ -138,6 +151,9 @@ def pack_resnet_bf16(sd: Dict[str, torch.Tensor], prefix: str = "feature_extract
             w = torch.nn.functional.pad(w, (0, 8 - w.shape[-1]))
         out += [w.to(torch.bfloat16).contiguous(), t32[i + 1], t32[i + 2]]
     out += [t32[-2].to(torch.bfloat16).contiguous(), t32[-1]]
+    w1 = sd[prefix + "conv1.weight"]
+    if tuple(w1.shape) == (64, 3, 7, 7):
+        out.append(pack_stem_bf16(w1))                   # optional last tensor: operands of the fused bf16 stem
     return out, blocks, planes
 
 

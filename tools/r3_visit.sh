@@ -30,6 +30,19 @@ for step in "$@"; do
     convbench)
       timeout 600 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --reps 10 --only l > "$OUT/conv_bf16_512.txt" 2>&1; cat "$OUT/conv_bf16_512.txt"
       timeout 600 python tools/conv_bench.py --bf16 --nimg 256 --warm 3 --reps 10 --only l > "$OUT/conv_bf16_256.txt" 2>&1; cat "$OUT/conv_bf16_256.txt";;
+    newtests)
+      rm -f gpurun_out/parity_report.jsonl
+      timeout 1500 python -m pytest tests/test_hip_bf16.py tests/test_hip_bench_geometry.py::test_configs2_bf16_forward_as_benched_vs_oracle tests/test_hip_model.py::test_eval_stream_input_pipeline_variants_agree -q -m gpu > "$OUT/pytest_new.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest_new.log"
+      tail -40 "$OUT/pytest_new.log"; cp gpurun_out/parity_report.jsonl "$OUT/parity_new.jsonl" 2>/dev/null;;
+    dmasweep)
+      timeout 900 python tools/conv_bench.py --bf16 --nimg 512 --warm 2 --reps 7 --only l --dma-sweep 0,1,2,3,4,5,6,7,8,9 > "$OUT/dma_sweep_512.txt" 2>&1; cat "$OUT/dma_sweep_512.txt"
+      timeout 900 python tools/conv_bench.py --bf16 --nimg 256 --warm 2 --reps 7 --only l --dma-sweep 0,1,3,4,5,7,9 > "$OUT/dma_sweep_256.txt" 2>&1; cat "$OUT/dma_sweep_256.txt";;
+    evalhost)
+      for inp in host resident; do
+        timeout 600 python tools/eval_stream.py --graphs 2000 --shape 256x341 --input $inp >> "$OUT/eval_stream.jsonl" 2>> "$OUT/eval_stream.err"; echo "eval $inp rc=$?"
+      done
+      timeout 600 python tools/eval_stream.py --graphs 4000 --shape 256x341 --input host --encoder-dtype bf16 --gnn-dtype bf16 >> "$OUT/eval_stream.jsonl" 2>> "$OUT/eval_stream.err"
+      cat "$OUT/eval_stream.jsonl";;
     *) echo "unknown step $step";;
   esac
 done
