@@ -291,6 +291,9 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
 #define RPG_TUNE_BF16_TILE 15     /* tile of the interleaved bf16 convolution kernel: -1 by shape (default) | 0: 64x64 | 1: 128x128 | 2: 256x64 | 3: 128x64 */
 #define RPG_TUNE_BF16_DMA 16      /* the LDS-DMA bf16 convolution kernel (buffer_load ... lds, counted vmcnt, up to 256 x 256 tiles on 8 waves):
                                      0: off | 1: by shape (default) | 10 + i: configuration i wherever eligible (experiments) */
+#define RPG_TUNE_BF16_PATCH 17    /* the patch kernel of the bf16 encoder's 3x3 / stride-1 convolutions (input patch resident in LDS, nine taps
+                                     read it at shifted slots; Cin % 64 == 0): 0: off | 1: for more than 64 output channels on >= 8192
+                                     pixels (default) | 2: on any eligible size | 3: as 2 with the 256 x 128 tile for every width */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

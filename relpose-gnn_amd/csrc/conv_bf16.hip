@@ -530,13 +530,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
         for (int j = 0; j < JB; ++j) weff[j] = live ? woff[j] : OOB;
     };
     refresh();
-    auto issue_step = [&](int im) {                       // all pieces of the next K step -> image im (compile-time index)
-#pragma unroll
-        for (int j = 0; j < JA; ++j)
-            dma_piece16(rsa, lds_raw + im * IMG_B + (wave + NW * j) * 1024, voff[j], 2 * c0);
-#pragma unroll
-        for (int j = 0; j < JB; ++j)
-            dma_piece16(rsw, lds_raw + im * IMG_B + BM * BK * 2 + (wave + NW * j) * 1024, weff[j], 2 * k0);
+    // piece jj (0 .. NJ-1: A pieces, then B pieces) of the next K step -> image im (compile-time indices)
+    auto issue_piece = [&](int jj, int im) {
+        if (jj < JA) dma_piece16(rsa, lds_raw + im * IMG_B + (wave + NW * jj) * 1024, voff[jj], 2 * c0);
+        else dma_piece16(rsw, lds_raw + im * IMG_B + BM * BK * 2 + (wave + NW * (jj - JA)) * 1024, weff[jj - JA], 2 * k0);
+    };
+    auto advance_k = [&]() {
         k0 += BK;
         c0 += BK;
         if (c0 >= a.Cin || k0 >= K) {
@@ -560,7 +559,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    auto compute = [&](int im) {                           // one K step on image im (compile-time index)
+    // one K step on image im, with the NJ pieces of step t + ST - 1 (-> image in) issued a few at a time in front of the k
+    // groups instead of in one clump behind the barrier (a wave issues in order: 8 DMA instructions in a row are ~600 cycles
+    // in which it feeds no MFMA)
+    auto compute = [&](int im, int in) {
         const unsigned char* L = lds_raw + im * IMG_B;
         bf16x8 fr[2][NR];
         auto read_group = [&](int set, int g) {
@@ -571,9 +573,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
             for (int j = 0; j < FN; ++j)
                 fr[set][FM + j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(L + b_blk + j * 32 * BK * 2 + cbyte[g]));
         };
+        constexpr int PPG = (NJ + KB - 1) / KB;             // pieces per k group
         read_group(0, 0);
 #pragma unroll
         for (int g = 0; g < KB; ++g) {
+#pragma unroll
+            for (int u = 0; u < PPG; ++u)
+                if (g * PPG + u < NJ) issue_piece(g * PPG + u, in);
             if (g + 1 < KB) read_group((g + 1) & 1, g + 1);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
@@ -590,21 +596,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
                 }
             }
         }
+        advance_k();
     };
 
     const int nk = K / BK;
     // prologue: steps 0 .. ST-2 in flight (steps past the end are all out of range: zero pieces, same instruction count)
 #pragma unroll
-    for (int s = 0; s < ST - 1; ++s) issue_step(s);
+    for (int s = 0; s < ST - 1; ++s) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) issue_piece(jj, s);
+        advance_k();
+    }
     // step t: its pieces have landed when at most (ST - 2) * NJ younger loads of this wave are outstanding; the barrier makes
-    // that true for every wave's pieces and retires image (t - 1) % ST = (t + ST - 1) % ST, the target of the loads issued next
+    // that true for every wave's pieces and retires image (t - 1) % ST = (t + ST - 1) % ST, the target of the loads issued next.
+    // lgkmcnt(0): this wave's operand reads of step t - 1 must be COMPLETE, not merely issued, before any wave may overwrite
+    // that image -- hipcc moves the last MFMAs of a step (register-only instructions, which a "memory" clobber does not pin)
+    // and the wait for their operands below the barrier; without the explicit wait a DMA piece of another wave could land
+    // under a read still queued in a busy LDS (seen once: the 128 x 64 tile with three workgroups per CU on layer 1, wrong
+    // in a few elements out of 8 M)
 #define RPG_DMA_STEP(IMX)                                                              \
     do {                                                                               \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * NJ) : "memory");           \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((ST - 2) * NJ) : "memory"); \
         __builtin_amdgcn_s_barrier();                                                  \
         asm volatile("" ::: "memory");   /* no LDS read of this step above the barrier */ \
-        issue_step((IMX + ST - 1) % ST);                                               \
-        compute(IMX);                                                                  \
+        compute(IMX, (IMX + ST - 1) % ST);                                             \
     } while (0)
     int t = 0;
     for (; t + ST <= nk; t += ST) {
@@ -617,10 +632,208 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
     if (t < nk) { RPG_DMA_STEP(1); ++t; }
     if (ST > 3 && t < nk) { RPG_DMA_STEP(2 % ST); ++t; }
 #undef RPG_DMA_STEP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the zero pieces of the steps past K: LDS becomes the epilogue slabs
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the zero pieces of the steps past K: LDS becomes the epilogue slabs
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     bf16_tile_epilogue<FM, FN, ST * IMG_B, NW>(acc, lds_raw, ep, m0, n0, M, N, wm, wn, lane, wave);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The patch kernel (round 3): 3x3 / stride 1 / pad 1 convolutions with the INPUT PATCH resident in LDS.
+//
+// Measured on the LDS-DMA kernel above (r3, 512 images): a 256 x 256 tile of layer 4 runs at 53 % of a CU's bf16 matrix rate
+// and what bounds it is the operand fill from L2 -- 64 KB per 64-deep K step, of which the A half is the SAME input pixels
+// nine times over (im2col: every pixel is fetched once per kernel tap).  Here K is walked channel-chunk major, tap minor:
+//   * per 32-channel chunk the input pixels under the tile are fetched ONCE into LDS as a patch [rows][P slots][32 ch]
+//     (64-byte slots, chunk-swizzled by slot) with a zero halo, and the nine taps read their A fragments from it at shifted
+//     slots: address(lane, tap) = slot(lane) + kh * P + kw -- one v_add per ds_read_b128;
+//   * the patch rows are VIRTUAL image rows: image n occupies rows n (H + 2) + 1 .. + H, rows n (H + 2) and n (H + 2) + H + 1
+//     are zero (top / bottom padding), slots 0 and W + 1 .. P - 1 of every row are zero; all zeros come from out-of-range
+//     DMA lanes, so a tile of BM consecutive output pixels may span rows and images freely;
+//   * P is a multiple of 16 slots: the swizzle term ((slot >> 2) & 3) of a lane's address then depends on kw only, and the
+//     per-lane address table is 3 (kw) x 2 (k group) x FM registers for the whole kernel;
+//   * the weights of one (tap, chunk) -- BN rows of 64 bytes -- stream through three LDS stages, two steps ahead; the patch
+//     of the next chunk goes into the second patch buffer one 1-KB piece per wave and step during the current chunk's taps
+//     0..7; every step issues exactly 1 + JB loads per wave (dummy pieces land in a scratch KB), which keeps the counted
+//     s_waitcnt vmcnt(1 + JB) exact.
+// L2 -> LDS traffic per 32-deep step of a 256 x 256 tile: 16 KB of weights + ~3-6 KB of patch, against 32 KB before.
+// Requirements: Cin % 64 == 0 (an even number of chunks), patch <= 64 KB per buffer, 32-bit offsets (launcher).
+struct PatchArgs {
+    const __bf16* x;
+    int H, W, Cin, Nimg, M, N, tiles_n;
+    int P, PR, patch_bytes, n_pieces;      // slots per patch row, patch rows, bytes per patch buffer (multiple of 1 KB), 1-KB pieces
+};
+
+__device__ __forceinline__ void dma_piece16_raw(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_byte_off, unsigned char* lds_base,
+                                                unsigned voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(lds_base + lds_byte_off), 16, voffset, soffset, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchArgs a, const __bf16* __restrict__ Wt, EpiB ep) {
+    constexpr int NW = WM * WN;
+    static_assert(NW == 8, "8 waves");
+    constexpr int FM = BM / WM / 32, FN = BN / WN / 32, NR = FM + FN;
+    constexpr int JB = BN / 16 / NW;                          // weight pieces (16 rows x 64 B) per wave and step
+    static_assert(BN % (16 * NW) == 0, "weight pieces must divide over the waves");
+    constexpr int BSTAGE = BN * 64;                           // bytes per weight stage
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NL = 1 + JB;                                // loads per wave and step
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    const int m0 = (tile / a.tiles_n) * BM;
+    const int n0 = (tile % a.tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int H = a.H, W = a.W, HW = a.H * a.W, P = a.P, HV = a.H + 2;
+    const int NC = a.Cin / 32;
+
+    // ---- geometry of the tile: first virtual row of the patch, first image
+    const int n_first = m0 / HW;
+    const int v0 = n_first * HV + (m0 - n_first * HW) / W;          // = v(m0) - 1: the row above the tile's first pixel
+    const int img = HW * a.Cin;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x) + (size_t)n_first * img, 0,
+                                                                          0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wt), 0, 0x7fffffff, 0x00020000);
+    const unsigned dummy_off = 2u * (unsigned)a.patch_bytes + 3u * BSTAGE;      // 1 KB nobody reads
+
+    // ---- patch pieces of this wave: piece q = wave + 8 t (t = 0 .. 7) covers 16-byte chunks 64 q .. 64 q + 63 of the buffer;
+    // chunk ci = (slot ci >> 2, physical chunk ci & 3) <- logical chunk (ci & 3) ^ ((slot >> 2) & 3) of that pixel
+    unsigned pvoff[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int ci = (wave + NW * t) * 64 + lane;
+        const int slot = ci >> 2;
+        const int lc = (ci & 3) ^ ((slot >> 2) & 3);
+        const int prow = slot / P, pcol = slot - prow * P;
+        const int v = v0 + prow;
+        const int n = v / HV, rr = v - n * HV - 1;
+        const bool ok = (wave + NW * t) < a.n_pieces && prow < a.PR && (unsigned)rr < (unsigned)H && pcol >= 1 && pcol <= W && n < a.Nimg;
+        pvoff[t] = ok ? 2u * (unsigned)((((n - n_first) * H + rr) * W + (pcol - 1)) * a.Cin + 8 * lc) : OOB;
+    }
+    // weight pieces: piece j covers rows 16 (wave + 8 j) .. + 15 of the stage; lane: row l >> 2, physical chunk l & 3
+    unsigned woff[JB];
+    {
+        const int r_in = lane >> 2;
+        const int lc = (lane & 3) ^ ((r_in >> 2) & 3);
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const int n = n0 + (wave + NW * j) * 16 + r_in;
+            woff[j] = n < a.N ? 2u * (unsigned)(n * 9 * a.Cin + 8 * lc) : OOB;
+        }
+    }
+    // patch piece t of chunk `chunk` -> patch buffer `buf` (dummy target when this wave has no t-th piece)
+    auto issue_patch = [&](int t, int buf, int chunk) {
+        const bool real = (wave + NW * t) < a.n_pieces;
+        const unsigned dst = real ? (unsigned)(buf * a.patch_bytes + (wave + NW * t) * 1024) : dummy_off;
+        dma_piece16_raw(rsa, dst, lds_raw, chunk < NC ? pvoff[t] : OOB, chunk * 64);
+    };
+    auto issue_dummy = [&]() { dma_piece16_raw(rsa, dummy_off, lds_raw, OOB, 0); };
+    // the weights of (chunk, tap) -> stage `stage`
+    auto issue_w = [&](int stage, int chunk, int tap) {
+        const bool live = chunk < NC;
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+            dma_piece16_raw(rsw, 2u * (unsigned)a.patch_bytes + (unsigned)(stage * BSTAGE + (wave + NW * j) * 1024), lds_raw,
+                            live ? woff[j] : OOB, (tap * a.Cin + chunk * 32) * 2);
+    };
+
+    // ---- A fragment addresses: pixel m of lane (i, lane & 31) -> slot s0 = (v(m) - 1 - v0) * P + c; tap (kh, kw) reads slot
+    // s0 + kh * P + kw; byte address = slot * 64 + 16 * (chunk ^ ((slot >> 2) & 3)), chunk = 2 g + half
+    const int half = lane >> 5;
+    unsigned a3[FM][3][2];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        int m = m0 + (wm * FM + i) * 32 + (lane & 31);
+        m = m < a.M ? m : a.M - 1;
+        const int n = m / HW, rem = m - n * HW, r = rem / W, c = rem - r * W;
+        const int s0 = (n * HV + r - v0) * P + c;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int t = s0 + kw;
+            const int e = half ^ ((t >> 2) & 3);
+            a3[i][kw][0] = (unsigned)(t * 64 + 16 * e);
+            a3[i][kw][1] = (unsigned)(t * 64 + 16 * (e ^ 2));
+        }
+    }
+    // B fragment addresses (inside stage 0): row lrow of the wave's j-th 32-channel block, chunk 2 g + half
+    unsigned cb[2];
+    {
+        const int lrow = lane & 31, sw = (lrow >> 2) & 3;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            cb[g] = 2u * (unsigned)a.patch_bytes + (unsigned)(wn * FN * 32 * 64 + lrow * 64 + 16 * ((2 * g + half) ^ sw));
+    }
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // one step = one tap of one chunk on patch buffer BUF and weight stage tap % 3
+    auto step = [&](int buf, int tap, int chunk) {
+        const int kh = tap / 3, kw = tap % 3;
+        const unsigned aoff = (unsigned)(buf * a.patch_bytes + kh * P * 64);      // wave-uniform
+        const int stage = tap % 3;
+        bf16x8 fr[2][NR];
+        auto read_group = [&](int g) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                fr[g][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds_raw + (a3[i][kw][g] + aoff)));
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                fr[g][FM + j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds_raw + cb[g] + stage * BSTAGE + j * 32 * 64));
+        };
+        // loads of this step: one patch piece of the next chunk (taps 0..7; tap 8: a dummy), then the weights of step s + 2
+        if (tap < 8) issue_patch(tap, buf ^ 1, chunk + 1);
+        else issue_dummy();
+        read_group(0);
+        if (tap + 2 < 9) issue_w((tap + 2) % 3, chunk, tap + 2);
+        else issue_w((tap + 2) % 3, chunk + 1, tap + 2 - 9);
+        read_group(1);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g][i], fr[g][FM + j], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- prologue: the first chunk's patch, the weights of steps 0 and 1 (the last NL loads are exactly what step 0's wait
+    // leaves outstanding)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) issue_patch(t, 0, 0);
+    issue_w(0, 0, 0);
+    issue_dummy();
+    issue_w(1, 0, 1);
+#define RPG_PATCH_STEP(BUF, TAP, CHUNK)                                                  \
+    do {                                                                                 \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL) : "memory");              \
+        __builtin_amdgcn_s_barrier();                                                    \
+        asm volatile("" ::: "memory");                                                   \
+        step(BUF, TAP, CHUNK);                                                           \
+    } while (0)
+    for (int cc = 0; cc < NC; cc += 2) {
+        RPG_PATCH_STEP(0, 0, cc); RPG_PATCH_STEP(0, 1, cc); RPG_PATCH_STEP(0, 2, cc);
+        RPG_PATCH_STEP(0, 3, cc); RPG_PATCH_STEP(0, 4, cc); RPG_PATCH_STEP(0, 5, cc);
+        RPG_PATCH_STEP(0, 6, cc); RPG_PATCH_STEP(0, 7, cc); RPG_PATCH_STEP(0, 8, cc);
+        RPG_PATCH_STEP(1, 0, cc + 1); RPG_PATCH_STEP(1, 1, cc + 1); RPG_PATCH_STEP(1, 2, cc + 1);
+        RPG_PATCH_STEP(1, 3, cc + 1); RPG_PATCH_STEP(1, 4, cc + 1); RPG_PATCH_STEP(1, 5, cc + 1);
+        RPG_PATCH_STEP(1, 6, cc + 1); RPG_PATCH_STEP(1, 7, cc + 1); RPG_PATCH_STEP(1, 8, cc + 1);
+    }
+#undef RPG_PATCH_STEP
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bf16_tile_epilogue<FM, FN, 160 * 1024, NW>(acc, lds_raw, ep, m0, n0, a.M, a.N, wm, wn, lane, wave);
 }
 
 int g_bf16_fused_stem = 1;   // RPG_TUNE_FUSED_STEM also selects the bf16 encoder's fused stem (stem_bf16.hip)
@@ -673,6 +886,38 @@ void launch_dma(const ConvArgsB& a, const __bf16* w, int M, int N, int K, const 
     }
     const int tn = (N + BN - 1) / BN, tm = (M + BM - 1) / BM;
     hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(64 * WM * WN), lds, s, a, w, M, N, K, ep, tn);
+}
+
+int g_bf16_patch = 1;    // RPG_TUNE_BF16_PATCH: the patch kernel for 3x3 / stride-1 convolutions: 0 off | 1 by shape | 2 wherever eligible
+
+// The patch kernel, if the shape is eligible (3x3, stride 1, pad 1, Cin % 64 == 0, patch <= 64 pieces, 32-bit offsets, LDS fits)
+template <int BM, int BN, int WM, int WN>
+bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, const EpiB& ep, hipStream_t s) {
+    if (c.KH != 3 || c.KW != 3 || c.stride != 1 || c.pad != 1 || (c.Cin & 63) || c.img_elems) return false;
+    const int H = c.H, W = c.W, HW = H * W;
+    PatchArgs a{};
+    a.x = c.x; a.H = H; a.W = W; a.Cin = c.Cin; a.Nimg = nimg; a.M = M; a.N = N;
+    a.tiles_n = (N + BN - 1) / BN;
+    a.P = (W + 2 + 15) / 16 * 16;
+    const int rows = (BM - 1) / W + 2, imgs = (BM - 1) / HW + 2;
+    a.PR = rows + 2 * (imgs - 1) + 2;
+    a.patch_bytes = (a.PR * a.P * 64 + 1023) / 1024 * 1024;
+    a.n_pieces = a.patch_bytes / 1024;
+    const int lds = 2 * a.patch_bytes + 3 * BN * 64 + 1024;
+    constexpr int slab = 8 * 32 * ((BN / WN / 32) * 32 + 4) * 4;
+    if (a.n_pieces > 64 || lds > 160 * 1024 || lds < slab) return false;
+    if ((long)(imgs + 1) * HW * c.Cin * 2 >= (1L << 31) || (long)N * 9 * c.Cin * 2 >= (1L << 31)) return false;
+    auto kern = conv3x3_bf16_patch_kernel<BM, BN, WM, WN>;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    static bool once[64] = {};
+    if (!once[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once[dev] = true;
+    }
+    const int tm = (M + BM - 1) / BM;
+    hipLaunchKernelGGL(kern, dim3(tm * a.tiles_n), dim3(512), lds, s, a, w, ep);
+    return true;
 }
 
 // configuration table of the LDS-DMA kernel (index = RPG_TUNE_BF16_DMA - 10); returns false if the index is unknown or the
@@ -777,6 +1022,7 @@ void bf16_set_bk(int bk) { g_bf16_bk = bk; }
 void bf16_set_fast(int on) { g_bf16_fast = on; }
 void bf16_set_tile(int t) { g_bf16_tile = t; }
 void bf16_set_dma(int v) { g_bf16_dma = v; }
+void bf16_set_patch(int v) { g_bf16_patch = v; }
 void bf16_set_fused_stem(int on) { g_bf16_fused_stem = on; }
 
 // fp32 [rows][ld_src] (first `cols` columns) -> bf16 dst[rows][ld_dst] at column offset col_off (cols % 8 == 0)
@@ -866,8 +1112,28 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
     const long span = 256 / ((long)ho * wo) + 2;
     const bool fast = g_bf16_fast && cin % 64 == 0 && span * h * wd * cin * 2 < (1L << 31) && (long)cout * K * 2 < (1L << 31);
     const bool dma_ok = span * h * wd * cin * 2 < (1L << 31) && (long)cout * K * 2 < (1L << 31);
-    if (dma_ok && g_bf16_dma >= 10 && launch_dma_config(g_bf16_dma - 10, a, wp, (int)M, cout, (int)K, ep, s)) {
-        // forced configuration (experiments)
+    // RPG_TUNE_BF16_DMA = 1: the LDS-DMA kernel by shape (measured at 256 / 512 images, tools/conv_bench.py --dma-sweep,
+    // profiles/r3_bf16_dma_sweep_*.txt): 256 x 64 tiles with two workgroups per CU for 64 output channels (layer 1: the operand
+    // fill from L2 bounds it, N is too small to amortise the A tile), 256 x 128 / K step 32 / two workgroups per CU up to 128
+    // channels and wherever 256 x 256 tiles would leave a quarter of the CUs idle, 256 x 256 (wave tile 128 x 64) otherwise
+    int dma_cfg = -1;
+    if (dma_ok && g_bf16_dma == 1 && M >= 8192 && cin % 32 == 0) {
+        const long t256 = ((M + 255) / 256) * ((cout + 255) / 256);
+        if (cout <= 64) dma_cfg = cin % 64 == 0 ? 5 : -1;
+        else if (cout <= 128 || 4 * t256 < 3L * num_cus() || cin % 64) dma_cfg = 7;
+        else dma_cfg = 0;
+    } else if (dma_ok && g_bf16_dma >= 10) {
+        dma_cfg = g_bf16_dma - 10;                    // forced configuration (experiments)
+    }
+    // 3x3 / stride 1: the patch kernel (input pixels fetched once per 32-channel chunk instead of once per tap)
+    bool done = false;
+    if (g_bf16_patch && kh == 3 && kw == 3 && stride == 1 && pad == 1 && (g_bf16_patch >= 2 || M >= 8192)) {
+        if (g_bf16_patch == 3) done = launch_patch<256, 128, 4, 2>(a, wp, n, (int)M, cout, ep, s);
+        else if (cout > 128) done = launch_patch<256, 256, 2, 4>(a, wp, n, (int)M, cout, ep, s);
+        else if (cout > 64) done = launch_patch<256, 128, 4, 2>(a, wp, n, (int)M, cout, ep, s);
+    }
+    if (done) {
+    } else if (dma_cfg >= 0 && launch_dma_config(dma_cfg, a, wp, (int)M, cout, (int)K, ep, s)) {
     } else if (fast && g_bf16_tile >= 0) {       // RPG_TUNE_BF16_TILE: forced tile of the interleaved kernel (experiments)
         if (g_bf16_tile == 0) launch_fast<64, 64, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);
         else if (g_bf16_tile == 1) launch_fast<128, 128, 2, 2>(a, wp, (int)M, cout, (int)K, ep, s);

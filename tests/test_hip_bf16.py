@@ -198,6 +198,46 @@ def test_conv_bf16_dma_configs(dev, cfg, n, h, w, cin, cout, k, stride, pad, res
     assert rel_err(y.float().cpu().permute(0, 3, 1, 2), ref) < (1e-4 if f32out else 1e-2)
 
 
+@pytest.mark.parametrize("mode", [2, 3], ids=["by_width", "tile256x128"])
+@pytest.mark.parametrize("n,h,w,cin,cout,res,relu", [
+    (40, 56, 56, 64, 64, True, True),       # layer-1 shape: 10 patch rows of 64 slots, 2 chunks
+    (24, 28, 28, 128, 128, True, True),     # layer-2 shape
+    (9, 14, 14, 256, 256, False, True),     # layer-3 shape: tiles span 2 images, ragged M (1764)
+    (70, 7, 7, 512, 512, True, True),       # layer-4 shape: tiles span 6-7 images (zero rows between them), 16 chunks
+    (3, 13, 17, 192, 72, True, False),      # odd sizes, ragged N, 6 chunks
+    (5, 8, 11, 64, 320, False, True),       # 256x341's last stage; N = 320: two channel tiles, the second ragged
+    (2, 5, 3, 128, 128, True, True),        # tiny image: 3 of 16 slots per patch row used, the whole batch inside one tile
+    (1, 64, 86, 64, 64, False, True),       # 256x341's first stage: 96 slots per row
+])
+def test_conv3x3_bf16_patch_kernel(dev, mode, n, h, w, cin, cout, res, relu):
+    """The patch kernel of the bf16 encoder (3x3 / stride 1 / pad 1 with the input patch resident in LDS; RPG_TUNE_BF16_PATCH = 2:
+    every eligible size, tile by output width; 3: the 256 x 128 tile everywhere) against F.conv2d on the same bf16 inputs in fp32:
+    tiles that span image rows and whole images (virtual zero rows), zero halo slots from out-of-range DMA lanes, ragged M / N,
+    2 .. 16 channel chunks through the two patch buffers and three weight stages."""
+    from relpose_gnn_amd import ops
+    x = _rand(n, cin, h, w, seed=31).bfloat16()
+    wt = _rand(cout, cin, 3, 3, seed=32, scale=(2.0 / (cin * 9)) ** 0.5).bfloat16()
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(33)) + 0.5
+    shift = _rand(cout, seed=34, scale=0.1)
+    ref = F.conv2d(x.float(), wt.float(), None, stride=1, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    r = None
+    if res:
+        r = _rand(*ref.shape, seed=35).bfloat16()
+        ref = ref + r.float()
+    if relu:
+        ref = F.relu(ref)
+    ops.set_tuning(ops.TUNE_BF16_PATCH, mode)
+    try:
+        y = ops.conv2d_bn_act_nhwc_bf16(x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev),
+                                        scale.to(dev), shift.to(dev), None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev),
+                                        stride=1, pad=1, relu=relu)
+    finally:
+        ops.set_tuning(ops.TUNE_BF16_PATCH, 1)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < 1e-2
+    assert float((got - ref).abs().mean() / ref.abs().mean().clamp(min=1e-30)) < 3e-3     # bf16 output rounding only
+
+
 @pytest.mark.parametrize("n,h,w", [(2, 224, 224), (1, 256, 341), (3, 37, 53), (2, 9, 5), (1, 64, 500), (5, 32, 40), (1, 1, 1)])
 def test_fused_stem_bf16(dev, n, h, w):
     """rpg_stem_conv7x7s2_bn_relu_maxpool_bf16 (fp32 NCHW in -> pooled bf16 NHWC out, bf16 MFMA) vs conv2d(7x7, s2, p3) on the

@@ -103,11 +103,20 @@ def main():
             if args.dma_sweep:
                 fl = 2.0 * n * ho * wo * cout * k * k * cin
                 cells = []
-                for cfg in [-1] + [int(v) for v in args.dma_sweep.split(",")]:
+                ops.set_tuning(ops.TUNE_BF16_PATCH, 0)
+                for cfg in [-1] + [int(v) for v in args.dma_sweep.split(",") if v.strip()]:
                     ops.set_tuning(ops.TUNE_BF16_DMA, 0 if cfg < 0 else 10 + cfg)
                     med, best = timeit(run, args.reps)
                     cells.append(f"{'base' if cfg < 0 else 'c%d' % cfg}:{med*1e3:6.1f}us/{fl/med/1e9:5.0f}TF")
                 ops.set_tuning(ops.TUNE_BF16_DMA, 1)
+                med, best = timeit(run, args.reps)
+                cells.append(f"auto:{med*1e3:6.1f}us/{fl/med/1e9:5.0f}TF")
+                if k == 3 and s == 1:
+                    for mode in (2, 3):
+                        ops.set_tuning(ops.TUNE_BF16_PATCH, mode)
+                        med, best = timeit(run, args.reps)
+                        cells.append(f"patch{mode}:{med*1e3:6.1f}us/{fl/med/1e9:5.0f}TF")
+                ops.set_tuning(ops.TUNE_BF16_PATCH, 1)
                 print(f"conv {name:6s} M={n*ho*wo:8d} N={cout:4d} K={k*k*cin:5d}  " + "  ".join(cells), flush=True)
                 continue
             med, best = timeit(run, args.reps)

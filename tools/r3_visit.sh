@@ -37,6 +37,14 @@ for step in "$@"; do
     dmasweep)
       timeout 900 python tools/conv_bench.py --bf16 --nimg 512 --warm 2 --reps 7 --only l --dma-sweep 0,1,2,3,4,5,6,7,8,9 > "$OUT/dma_sweep_512.txt" 2>&1; cat "$OUT/dma_sweep_512.txt"
       timeout 900 python tools/conv_bench.py --bf16 --nimg 256 --warm 2 --reps 7 --only l --dma-sweep 0,1,3,4,5,7,9 > "$OUT/dma_sweep_256.txt" 2>&1; cat "$OUT/dma_sweep_256.txt";;
+    patchsweep)
+      timeout 900 python tools/conv_bench.py --bf16 --nimg 512 --warm 2 --reps 7 --only l --dma-sweep 0,5,7 > "$OUT/patch_sweep_512.txt" 2>&1; cat "$OUT/patch_sweep_512.txt"
+      timeout 900 python tools/conv_bench.py --bf16 --nimg 256 --warm 2 --reps 7 --only l --dma-sweep 0,5,7 > "$OUT/patch_sweep_256.txt" 2>&1; cat "$OUT/patch_sweep_256.txt";;
+    prof1)
+      export TMPDIR=/tmp; cd /tmp
+      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_b1" -o t -- python3 "$R/bench.py" --steps 30 --warmup 5 --cpu-baseline-seconds 0 --graphs 1 --streams 1 --no-kernel-timing > "$OUT/trace_b1.log" 2>&1
+      cd "$R"; f=$(ls "$OUT"/trace_b1/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 tools/rocprof_summary.py "$f" "$OUT/kernel_stats_b1.txt" > /dev/null; head -40 "$OUT/kernel_stats_b1.txt"; rm -f "$OUT"/trace_b1/*kernel_trace.csv
+      tail -2 "$OUT/trace_b1.log" | cut -c1-300;;
     evalhost)
       for inp in host resident; do
         timeout 600 python tools/eval_stream.py --graphs 2000 --shape 256x341 --input $inp >> "$OUT/eval_stream.jsonl" 2>> "$OUT/eval_stream.err"; echo "eval $inp rc=$?"
