@@ -307,6 +307,28 @@ def main():
                        "what": f"the same kernel alone at {gi} graphs per launch ({round(v['work'] / v['launches'] / 1e6)} MB "
                                "algorithmic, back-to-back launches on one stream)"}
         del msg, gp, big
+    # single-graph latency (the reference's own evaluation loop is batch_size=1, testing/test.py:192): one 8-node graph per
+    # call, host-synchronised after every call (median of 40) and streamed (40 calls, one synchronisation).  Reported next
+    # to `value`, never as `value`.
+    lat1 = None
+    if rank == 0 and args.encoder_dtype == "f32" and not args.no_kernel_timing:
+        d1 = fc_batch(x[:NODES], NODES)
+        for _ in range(5):
+            model(d1)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(40):
+            t0 = time.perf_counter()
+            model(d1)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        for _ in range(40):
+            model(d1)
+        torch.cuda.synchronize()
+        lat1 = {"latency_1graph_ms": round(1e3 * sorted(ts)[len(ts) // 2], 4),
+                "streamed_1graph_ms": round(1e3 * (time.perf_counter() - t0) / 40, 4),
+                "image_streams": int(getattr(model, "small_batch_streams", 1))}
     if under_launcher:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -423,6 +445,9 @@ def main():
             if scatter_iso is not None:
                 other["scatter_isolated"] = scatter_iso
             line["other_kernels"] = other
+        if lat1 is not None:
+            line["latency_1graph"] = dict(lat1, what="one 8-node 224x224 graph per forward (the reference's batch_size=1 loop): wall time "
+                                                    "per call with a host synchronisation after each / per call when 40 calls are streamed")
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)

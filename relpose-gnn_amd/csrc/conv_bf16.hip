@@ -559,41 +559,38 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // one K step on image im, with the NJ pieces of step t + ST - 1 (-> image in) issued a few at a time in front of the k
-    // groups instead of in one clump behind the barrier (a wave issues in order: 8 DMA instructions in a row are ~600 cycles
-    // in which it feeds no MFMA)
-    auto compute = [&](int im, int in) {
+    // One K step on image im; the NJ pieces of step t + ST - 1 go to image in.  The schedule is pinned (sched_barrier after
+    // every MFMA slot, as in the f32 engines): left to itself hipcc keeps ONE fragment set and serialises read - wait - MFMA,
+    // which leaves the matrix pipe idle for an LDS round trip per k group (measured r3: 53 % MFMA rate inside a tile whether
+    // the fill traffic was 64 KB or 37 KB per step).  Here group g + 1's fragments are read into the other register set one
+    // at a time behind group g's MFMAs, and the DMA pieces are spread over the step's MFMA slots.
+    bf16x8 fr[2][NR];
+    auto read_frag = [&](int set, int g, int rj, int im) {
         const unsigned char* L = lds_raw + im * IMG_B;
-        bf16x8 fr[2][NR];
-        auto read_group = [&](int set, int g) {
+        const unsigned char* p = rj < FM ? L + a_blk + rj * 32 * BK * 2 + cbyte[g] : L + b_blk + (rj - FM) * 32 * BK * 2 + cbyte[g];
+        fr[set][rj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
+    };
+    auto compute = [&](int im, int in) {
+        constexpr int G = FM * FN, SLOTS = KB * G;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
-                fr[set][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(L + a_blk + i * 32 * BK * 2 + cbyte[g]));
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                fr[set][FM + j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(L + b_blk + j * 32 * BK * 2 + cbyte[g]));
-        };
-        constexpr int PPG = (NJ + KB - 1) / KB;             // pieces per k group
-        read_group(0, 0);
+        for (int rj = 0; rj < NR; ++rj) read_frag(0, 0, rj, im);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < KB; ++g) {
 #pragma unroll
-            for (int u = 0; u < PPG; ++u)
-                if (g * PPG + u < NJ) issue_piece(g * PPG + u, in);
-            if (g + 1 < KB) read_group((g + 1) & 1, g + 1);
+            for (int ms = 0; ms < G; ++ms) {
+                const int i = ms / FN, j = ms % FN, slot = g * G + ms;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g & 1][i], fr[g & 1][FM + j], acc[i][j], 0, 0, 0);
+                // side jobs of this MFMA slot: fragment reads of the next group (NR of them over G slots), DMA pieces (NJ over SLOTS)
+                if (g + 1 < KB) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g & 1][i], fr[g & 1][FM + j], acc[i][j], 0, 0, 0);
-            // the next group's operand reads go one at a time behind this group's MFMAs (left alone, hipcc serialises
-            // read - wait - MFMA with a single fragment set): MFMA, ds_read, MFMA, ds_read, ...
-            if (g + 1 < KB) {
-#pragma unroll
-                for (int u = 0; u < FM * FN; ++u) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA
-                    if (u < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // one ds_read
+                    for (int rk = ms * NR / G; rk < (ms + 1) * NR / G; ++rk)       // B fragments first: the group's first MFMAs need them
+                        read_frag((g + 1) & 1, g + 1, rk < FN ? FM + rk : rk - FN, im);
                 }
+#pragma unroll
+                for (int pj = slot * NJ / SLOTS; pj < (slot + 1) * NJ / SLOTS; ++pj) issue_piece(pj, in);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         advance_k();
@@ -777,34 +774,58 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // one step = one tap of one chunk on patch buffer BUF and weight stage tap % 3
+    // One step = one tap of one chunk on patch buffer `buf` and weight stage tap % 3: two k groups of FM * FN MFMAs.  Pinned
+    // schedule (see the LDS-DMA kernel): group 1's fragments are read behind group 0's MFMAs; and because the patch of a chunk
+    // is complete from its first tap on, the NEXT tap's group-0 A fragments are read behind group 1's MFMAs, before the
+    // barrier -- after it only the two weight fragments of the new stage (and at a chunk's first tap the A fragments) are
+    // exposed.  Loads of the step: one patch piece of the next chunk (taps 0..7; tap 8: a dummy) in the first MFMA slot, the
+    // weights of step s + 2 spread over the following slots.
+    bf16x8 fr[2][NR];
+    auto read_a = [&](int set, int g, int i, int buf, int tap) {
+        const unsigned aoff = (unsigned)(buf * a.patch_bytes + (tap / 3) * P * 64);      // wave-uniform
+        fr[set][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds_raw + (a3[i][tap % 3][g] + aoff)));
+    };
+    auto read_b = [&](int set, int g, int j, int tap) {
+        fr[set][FM + j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds_raw + cb[g] + (tap % 3) * BSTAGE + j * 32 * 64));
+    };
     auto step = [&](int buf, int tap, int chunk) {
-        const int kh = tap / 3, kw = tap % 3;
-        const unsigned aoff = (unsigned)(buf * a.patch_bytes + kh * P * 64);      // wave-uniform
-        const int stage = tap % 3;
-        bf16x8 fr[2][NR];
-        auto read_group = [&](int g) {
+        constexpr int G = FM * FN;
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap == 0) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
-                fr[g][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds_raw + (a3[i][kw][g] + aoff)));
+            for (int i = 0; i < FM; ++i) read_a(0, 0, i, buf, tap);
+        }
 #pragma unroll
-            for (int j = 0; j < FN; ++j)
-                fr[g][FM + j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds_raw + cb[g] + stage * BSTAGE + j * 32 * 64));
-        };
-        // loads of this step: one patch piece of the next chunk (taps 0..7; tap 8: a dummy), then the weights of step s + 2
-        if (tap < 8) issue_patch(tap, buf ^ 1, chunk + 1);
-        else issue_dummy();
-        read_group(0);
-        if (tap + 2 < 9) issue_w((tap + 2) % 3, chunk, tap + 2);
-        else issue_w((tap + 2) % 3, chunk + 1, tap + 2 - 9);
-        read_group(1);
+        for (int j = 0; j < FN; ++j) read_b(0, 0, j, tap);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int ms = 0; ms < G; ++ms) {                      // k group 0
+            const int i = ms / FN, j = ms % FN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[0][i], fr[0][FM + j], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+            for (int rk = ms * NR / G; rk < (ms + 1) * NR / G; ++rk) {
+                if (rk < FN) read_b(1, 1, rk, tap);
+                else read_a(1, 1, rk - FN, buf, tap);
+            }
+            if (ms == 0) {
+                if (tap < 8) issue_patch(tap, buf ^ 1, chunk + 1);
+                else issue_dummy();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g][i], fr[g][FM + j], acc[i][j], 0, 0, 0);
+        for (int ms = 0; ms < G; ++ms) {                      // k group 1
+            const int i = ms / FN, j = ms % FN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[1][i], fr[1][FM + j], acc[i][j], 0, 0, 0);
+            if (ms == 0) {
+                if (tap + 2 < 9) issue_w((tap + 2) % 3, chunk, tap + 2);
+                else issue_w((tap + 2) % 3, chunk + 1, tap + 2 - 9);
+            }
+            // next tap's group-0 A fragments (set 0 is free once group 0 has issued), early in the group: the wait in front of
+            // the barrier must not find them still in flight
+            if (tap < 8 && ms < FM) read_a(0, 0, ms, buf, tap + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     // ---- prologue: the first chunk's patch, the weights of steps 0 and 1 (the last NL loads are exactly what step 0's wait

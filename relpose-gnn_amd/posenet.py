@@ -114,6 +114,8 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         # and the parts run concurrently, which fills the tile-quantisation tails of one part's kernels with the other
         # part's work).  Needs the host-side slice table of relpose_gnn_amd.graph.Batch; other inputs use one stream.
         self.hip_streams = 2
+        # streams the IMAGES of a batch too small to be cut at graph boundaries are spread over (see _encode_small)
+        self.small_batch_streams = 4
         # optional explicit schedule (experiments / tuning): [(first graph, last graph + 1, stream slot), ...] in issue order;
         # groups on the same slot run one after the other.  None = `hip_streams` equal contiguous groups, one per stream.
         self.stream_schedule: Optional[List[Tuple[int, int, int]]] = None
@@ -378,7 +380,7 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         parts = self._partition(data, x.size(0), edge_index.size(1)) if fast else None
         if parts is not None and edge_index.dtype == torch.int64 and edge_index.dim() == 2 and edge_index.is_contiguous():
             return self._forward_streams(lib, x, edge_index, parts)
-        feat = self._enc.run(self.feature_extractor.state_dict, "", x)            # posenet.py:1037
+        feat = self._encode_small(x)                                              # posenet.py:1037
 
         n, d = feat.shape
         if self.use_attention:                                                    # posenet.py:1040-1041
@@ -427,6 +429,32 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
             abs_pose = ops.linear_gather([(node_f, lo), (node_f, hi)], self._extra["heads_pair_w"],
                                          self._extra["heads_pair_b"], e)
         return abs_pose, rel_pose, (edge_index_knn if k is not None else edge_index)
+
+    def _encode_small(self, x: torch.Tensor) -> torch.Tensor:
+        """The encoder for a batch that cannot be cut at graph boundaries (one graph: the reference's batch_size=1 loop,
+        testing/test.py:192).  Images are independent, so the 8 images of a graph are spread over ``small_batch_streams`` HIP
+        streams: at this size every kernel is a few hundred workgroups of a few microseconds and the forward is a chain of
+        ~130 launch latencies (measured r3: 29 Winograd launches of 28 us + 29 fix-ups of 6 us for 8 images) -- two or four
+        such chains side by side share the chip.  One stream for larger batches (they fill the chip by themselves)."""
+        n = x.size(0)
+        k = min(int(self.small_batch_streams), n)
+        if k < 2 or n > 32 or torch.cuda.is_current_stream_capturing():
+            return self._enc.run(self.feature_extractor.state_dict, "", x)
+        dev = x.device
+        while len(self._streams) < k:
+            self._streams.append(torch.cuda.Stream(device=dev))
+        feat = torch.empty((n, self.feature_extractor.fc.out_features), dtype=torch.float32, device=dev)
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        for p in range(k):
+            i0, i1 = n * p // k, n * (p + 1) // k
+            st = self._streams[p]
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                self._enc.run(self.feature_extractor.state_dict, "", x[i0:i1], slot=(100, p), out=feat[i0:i1])
+            cur.wait_stream(st)
+        return feat
 
     def _forward_streams(self, lib, x, edge_index, parts):
         """Fast path (use_AP, no kNN / dropout / extra attention) on ``len(parts)`` concurrent streams."""

@@ -102,7 +102,7 @@ class EncoderRunner:
                 self._packed = pack_resnet(sd, prefix, wino_fn=ops.wino43_transform_weights)
         self._ptrs = L.ptr_array([None if t is None else t.data_ptr() for t in self._packed[0]])
 
-    def run(self, state_dict_fn, prefix: str, x_nchw: torch.Tensor, slot: int = 0) -> torch.Tensor:
+    def run(self, state_dict_fn, prefix: str, x_nchw: torch.Tensor, slot: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if not x_nchw.is_cuda:
             raise RuntimeError("the encoder runs on the GPU only (HIP kernels, no CPU fallback); got " + str(x_nchw.device))
         if x_nchw.dtype != torch.float32 or x_nchw.dim() != 4 or x_nchw.shape[1] != 3:
@@ -117,7 +117,9 @@ class EncoderRunner:
         bf16 = self.dtype == "bf16"
         nbytes = (lib.rpg_resnet_bf16_workspace_bytes if bf16 else lib.rpg_resnet_workspace_bytes)(n, h, w, planes_c)
         ws = self._pool.get(slot, nbytes, x.device)      # one workspace per concurrent stream slot (grows, never shrinks)
-        feat = torch.empty((n, feat_dim), dtype=torch.float32, device=x.device)
+        feat = out if out is not None else torch.empty((n, feat_dim), dtype=torch.float32, device=x.device)
+        if feat.shape != (n, feat_dim) or feat.dtype != torch.float32 or not feat.is_contiguous() or feat.device != x.device:
+            raise ValueError("out must be a contiguous fp32 [N, feat_dim] tensor on the input's device")
         fwd = lib.rpg_resnet_forward_bf16 if bf16 else lib.rpg_resnet_forward_f32
         rc = fwd(self._ptrs, len(tensors), L.int_array(blocks), planes_c, feat_dim, x.data_ptr(), n, h, w, feat.data_ptr(),
                  ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
