@@ -467,9 +467,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
     constexpr int NW = WM * WN;
     constexpr int CH = BK / 8, RPG = 64 / CH;                  // 16-byte chunks per row; rows per 1-KB piece
     constexpr int NA = BM / RPG, NB = BN / RPG;                // pieces per image
-    static_assert(NA % NW == 0 && NB % NW == 0, "pieces must divide evenly over the waves");
+    static_assert(NA % NW == 0 && (NB % NW == 0 || NB < NW), "pieces must divide evenly over the waves");
     static_assert(BK == 64 || BK == 32, "K step");
-    constexpr int JA = NA / NW, JB = NB / NW, NJ = JA + JB;    // pieces per wave and step
+    // pieces per wave and step; a narrow weight tile (NB < NW pieces) gives the waves without one a dummy piece (out of
+    // range -> zeros into a spare KB behind the images), so that every wave issues the same number of loads per step
+    constexpr int JA = NA / NW, JB = NB >= NW ? NB / NW : 1, NJ = JA + JB;
+    constexpr bool B_DUMMY = NB < NW;
     constexpr int FM = BM / WM / 32, FN = BN / WN / 32, KB = BK / 16, NR = FM + FN;
     constexpr int IMG_B = (BM + BN) * BK * 2;                  // bytes per LDS image
     constexpr unsigned OOB = 0x80000000u;
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
         const int n = n0 + (wave + NW * j) * RPG + r_in;
-        woff[j] = n < N ? 2u * (unsigned)(n * K + 8 * lc) : OOB;
+        woff[j] = n < N && (!B_DUMMY || wave < NB) ? 2u * (unsigned)(n * K + 8 * lc) : OOB;
     }
     int kh = 0, kw = 0, c0 = 0, k0 = 0;                   // wave-uniform position of the next fetch (K % BK == 0)
     auto refresh = [&]() {                                // offsets of tap (kh, kw); everything out of range past K
@@ -533,6 +536,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
     // piece jj (0 .. NJ-1: A pieces, then B pieces) of the next K step -> image im (compile-time indices)
     auto issue_piece = [&](int jj, int im) {
         if (jj < JA) dma_piece16(rsa, lds_raw + im * IMG_B + (wave + NW * jj) * 1024, voff[jj], 2 * c0);
+        else if (B_DUMMY && wave >= NB) dma_piece16(rsw, lds_raw + ST * IMG_B, OOB, 0);
         else dma_piece16(rsw, lds_raw + im * IMG_B + BM * BK * 2 + (wave + NW * (jj - JA)) * 1024, weff[jj - JA], 2 * k0);
     };
     auto advance_k = [&]() {
@@ -895,7 +899,7 @@ void launch_fast(const ConvArgsB& a, const __bf16* w, int M, int N, int K, const
 
 template <int BM, int BN, int WM, int WN, int BK, int ST>
 void launch_dma(const ConvArgsB& a, const __bf16* w, int M, int N, int K, const EpiB& ep, hipStream_t s) {
-    constexpr int lds = ST * (BM + BN) * BK * 2;
+    constexpr int lds = ST * (BM + BN) * BK * 2 + 1024;       // + the spare KB of the dummy pieces
     static_assert(lds <= 160 * 1024, "LDS images do not fit a CU");
     auto kern = conv_bf16_dma_kernel<BM, BN, WM, WN, BK, ST>;
     int dev = 0;
@@ -956,6 +960,9 @@ bool launch_dma_config(int cfg, const ConvArgsB& a, const __bf16* w, int M, int 
         case 7: if (!k32) return false; launch_dma<256, 128, 4, 2, 32, 3>(a, w, M, N, K, ep, s); return true;   // 72 KB: 2 workgroups / CU
         case 8: if (!k64) return false; launch_dma<128, 128, 2, 2, 64, 3>(a, w, M, N, K, ep, s); return true;   // 96 KB
         case 9: if (!k32) return false; launch_dma<128, 64, 2, 2, 32, 4>(a, w, M, N, K, ep, s); return true;    // 48 KB: 3 workgroups / CU
+        case 10: if (!k32) return false; launch_dma<512, 128, 4, 2, 32, 3>(a, w, M, N, K, ep, s); return true;  // 120 KB, wave 128 x 64
+        case 11: if (!k32) return false; launch_dma<1024, 64, 8, 1, 32, 2>(a, w, M, N, K, ep, s); return true;  // 136 KB, wave 128 x 64, N = 64
+        case 12: if (!k64) return false; launch_dma<512, 64, 8, 1, 64, 2>(a, w, M, N, K, ep, s); return true;   // 144 KB, wave 64 x 64
         default: return false;
     }
 }
@@ -1132,7 +1139,8 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
     // first image of a tile (whose <= 256 rows span at most 256 / (ho*wo) + 2 images)
     const long span = 256 / ((long)ho * wo) + 2;
     const bool fast = g_bf16_fast && cin % 64 == 0 && span * h * wd * cin * 2 < (1L << 31) && (long)cout * K * 2 < (1L << 31);
-    const bool dma_ok = span * h * wd * cin * 2 < (1L << 31) && (long)cout * K * 2 < (1L << 31);
+    const long span1k = 1024 / ((long)ho * wo) + 2;          // the widest DMA tile has 1024 rows
+    const bool dma_ok = span1k * h * wd * cin * 2 < (1L << 31) && (long)cout * K * 2 < (1L << 31);
     // RPG_TUNE_BF16_DMA = 1: the LDS-DMA kernel by shape (measured at 256 / 512 images, tools/conv_bench.py --dma-sweep,
     // profiles/r3_bf16_dma_sweep_*.txt): 256 x 64 tiles with two workgroups per CU for 64 output channels (layer 1: the operand
     // fill from L2 bounds it, N is too small to amortise the A tile), 256 x 128 / K step 32 / two workgroups per CU up to 128
@@ -1149,9 +1157,13 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
     // 3x3 / stride 1: the patch kernel (input pixels fetched once per 32-channel chunk instead of once per tap)
     bool done = false;
     if (g_bf16_patch && kh == 3 && kw == 3 && stride == 1 && pad == 1 && (g_bf16_patch >= 2 || M >= 8192)) {
+        // measured (tools/conv_bench.py --dma-sweep, r3): from 256 output channels up the patch kernel beats the im2col DMA kernel
+        // by 5-10 %; 256 x 256 tiles where they occupy at least three quarters of the CUs, else 256 x 128 (layer 4 at 256 images:
+        // 98 vs 196 tiles, 98 vs 68 us); at 128 channels the DMA kernel's 256 x 128 / K-step-32 configuration is faster
+        const long t256 = ((M + 255) / 256) * ((cout + 255) / 256);
         if (g_bf16_patch == 3) done = launch_patch<256, 128, 4, 2>(a, wp, n, (int)M, cout, ep, s);
-        else if (cout > 128) done = launch_patch<256, 256, 2, 4>(a, wp, n, (int)M, cout, ep, s);
-        else if (cout > 64) done = launch_patch<256, 128, 4, 2>(a, wp, n, (int)M, cout, ep, s);
+        else if (cout > 128 && 4 * t256 >= 3L * num_cus()) done = launch_patch<256, 256, 2, 4>(a, wp, n, (int)M, cout, ep, s);
+        else if (cout > 128 || g_bf16_patch == 2) done = launch_patch<256, 128, 4, 2>(a, wp, n, (int)M, cout, ep, s);
     }
     if (done) {
     } else if (dma_cfg >= 0 && launch_dma_config(dma_cfg, a, wp, (int)M, cout, (int)K, ep, s)) {
