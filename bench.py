@@ -360,10 +360,15 @@ def main():
             tf = c["work"] / (c["ms"] * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": BF16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(tf / BF16_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
-                                "kernel": "conv_bf16_fast_kernel / conv_bf16_kernel (implicit-GEMM conv, v_mfma_f32_32x32x16_bf16)",
+                                "kernel": "conv3x3_bf16_patch_kernel (3x3/s1 from 256 channels: input patch resident in LDS) / "
+                                          "conv_bf16_dma_kernel (implicit GEMM, operands by LDS-DMA, counted vmcnt) / "
+                                          "stem_pool_bf16_kernel (fused stem), all on v_mfma_f32_32x32x16_bf16",
                                 "launches": c["launches"], "avg_launch_ms": round(c["ms"] / c["launches"], 4),
-                                "note": "128x128-tile kernels: the layer-1 shapes are HBM-bound at this rate (DESIGN.md), the "
-                                        "others are bound by per-tile prologue / epilogue at 9-72 K steps per tile"}
+                                "what": "achieved = ALGORITHMIC FLOP of all the encoder's convolution launches (2 * pixels * Cout * "
+                                        "kh * kw * Cin; the stem as 7x7x3) / their summed HIP-event durations in the one-stream pass",
+                                "note": "inside a tile the 256 x 256 kernels run at ~5.3 TFLOP/s per CU (54 % of 2.5 PFLOP/s / 256; "
+                                        "the clock sits near 1.9 GHz under bf16 MFMA load); the rest is tile quantisation (49 * 2^k "
+                                        "tiles on 256 CUs) and the LDS-read-bound 64- and 128-channel layers (DESIGN.md section 5)"}
             if kt["linear"]["launches"]:
                 v = kt["linear"]
                 line["other_kernels"] = {"linear": {"achieved": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",

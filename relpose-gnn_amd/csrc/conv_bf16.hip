@@ -467,12 +467,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
     constexpr int NW = WM * WN;
     constexpr int CH = BK / 8, RPG = 64 / CH;                  // 16-byte chunks per row; rows per 1-KB piece
     constexpr int NA = BM / RPG, NB = BN / RPG;                // pieces per image
-    static_assert(NA % NW == 0 && (NB % NW == 0 || NB < NW), "pieces must divide evenly over the waves");
+    static_assert(NA % NW == 0 && NB % NW == 0, "pieces must divide evenly over the waves");
     static_assert(BK == 64 || BK == 32, "K step");
-    // pieces per wave and step; a narrow weight tile (NB < NW pieces) gives the waves without one a dummy piece (out of
-    // range -> zeros into a spare KB behind the images), so that every wave issues the same number of loads per step
-    constexpr int JA = NA / NW, JB = NB >= NW ? NB / NW : 1, NJ = JA + JB;
-    constexpr bool B_DUMMY = NB < NW;
+    constexpr int JA = NA / NW, JB = NB / NW, NJ = JA + JB;    // pieces per wave and step
     constexpr int FM = BM / WM / 32, FN = BN / WN / 32, KB = BK / 16, NR = FM + FN;
     constexpr int IMG_B = (BM + BN) * BK * 2;                  // bytes per LDS image
     constexpr unsigned OOB = 0x80000000u;
@@ -517,7 +514,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
         const int n = n0 + (wave + NW * j) * RPG + r_in;
-        woff[j] = n < N && (!B_DUMMY || wave < NB) ? 2u * (unsigned)(n * K + 8 * lc) : OOB;
+        woff[j] = n < N ? 2u * (unsigned)(n * K + 8 * lc) : OOB;
     }
     int kh = 0, kw = 0, c0 = 0, k0 = 0;                   // wave-uniform position of the next fetch (K % BK == 0)
     auto refresh = [&]() {                                // offsets of tap (kh, kw); everything out of range past K
@@ -536,7 +533,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
     // piece jj (0 .. NJ-1: A pieces, then B pieces) of the next K step -> image im (compile-time indices)
     auto issue_piece = [&](int jj, int im) {
         if (jj < JA) dma_piece16(rsa, lds_raw + im * IMG_B + (wave + NW * jj) * 1024, voff[jj], 2 * c0);
-        else if (B_DUMMY && wave >= NB) dma_piece16(rsw, lds_raw + ST * IMG_B, OOB, 0);
         else dma_piece16(rsw, lds_raw + im * IMG_B + BM * BK * 2 + (wave + NW * (jj - JA)) * 1024, weff[jj - JA], 2 * k0);
     };
     auto advance_k = [&]() {
@@ -899,7 +895,7 @@ void launch_fast(const ConvArgsB& a, const __bf16* w, int M, int N, int K, const
 
 template <int BM, int BN, int WM, int WN, int BK, int ST>
 void launch_dma(const ConvArgsB& a, const __bf16* w, int M, int N, int K, const EpiB& ep, hipStream_t s) {
-    constexpr int lds = ST * (BM + BN) * BK * 2 + 1024;       // + the spare KB of the dummy pieces
+    constexpr int lds = ST * (BM + BN) * BK * 2;              // (256 x 64 / K 64 / 2 images = 80 KB exactly: two workgroups per CU)
     static_assert(lds <= 160 * 1024, "LDS images do not fit a CU");
     auto kern = conv_bf16_dma_kernel<BM, BN, WM, WN, BK, ST>;
     int dev = 0;
@@ -960,9 +956,9 @@ bool launch_dma_config(int cfg, const ConvArgsB& a, const __bf16* w, int M, int 
         case 7: if (!k32) return false; launch_dma<256, 128, 4, 2, 32, 3>(a, w, M, N, K, ep, s); return true;   // 72 KB: 2 workgroups / CU
         case 8: if (!k64) return false; launch_dma<128, 128, 2, 2, 64, 3>(a, w, M, N, K, ep, s); return true;   // 96 KB
         case 9: if (!k32) return false; launch_dma<128, 64, 2, 2, 32, 4>(a, w, M, N, K, ep, s); return true;    // 48 KB: 3 workgroups / CU
-        case 10: if (!k32) return false; launch_dma<512, 128, 4, 2, 32, 3>(a, w, M, N, K, ep, s); return true;  // 120 KB, wave 128 x 64
-        case 11: if (!k32) return false; launch_dma<1024, 64, 8, 1, 32, 2>(a, w, M, N, K, ep, s); return true;  // 136 KB, wave 128 x 64, N = 64
-        case 12: if (!k64) return false; launch_dma<512, 64, 8, 1, 64, 2>(a, w, M, N, K, ep, s); return true;   // 144 KB, wave 64 x 64
+        // (measured and removed, r3: 512 x 128 / 1024 x 64 / 512 x 64 tiles with 128 x 64 wave tiles for the narrow layers 1-2 --
+        // 280-290 us on layer 1 against 205 us for configuration 5, 190 us on layer 2 against 160 us for configuration 7: fewer,
+        // fatter workgroups lose more to the one-workgroup-per-CU prologue / epilogue than the wave tile wins in LDS reads)
         default: return false;
     }
 }

@@ -115,7 +115,7 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         # part's work).  Needs the host-side slice table of relpose_gnn_amd.graph.Batch; other inputs use one stream.
         self.hip_streams = 2
         # streams the IMAGES of a batch too small to be cut at graph boundaries are spread over (see _encode_small)
-        self.small_batch_streams = 4
+        self.small_batch_streams = 1
         # optional explicit schedule (experiments / tuning): [(first graph, last graph + 1, stream slot), ...] in issue order;
         # groups on the same slot run one after the other.  None = `hip_streams` equal contiguous groups, one per stream.
         self.stream_schedule: Optional[List[Tuple[int, int, int]]] = None
@@ -438,7 +438,7 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         such chains side by side share the chip.  One stream for larger batches (they fill the chip by themselves)."""
         n = x.size(0)
         k = min(int(self.small_batch_streams), n)
-        if k < 2 or n > 32 or torch.cuda.is_current_stream_capturing():
+        if k < 2 or n > 32:
             return self._enc.run(self.feature_extractor.state_dict, "", x)
         dev = x.device
         while len(self._streams) < k:
