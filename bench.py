@@ -402,16 +402,18 @@ def main():
             }
             # PMC counters cannot be read from inside the process: they come from a COMMITTED rocprofv3 --pmc profile of
             # this command, used only if it was taken at this batch size, and labelled with the kernel sources it saw
-            from relpose_gnn_amd.build import source_digest
-            tpath = os.path.join(ROOT, "profiles", "r2_pmc_wino43.json")
-            if os.path.exists(tpath):
+            from relpose_gnn_amd.build import WINOGRAD_SOURCES, source_digest
+            tpath = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_pmc_wino43.json") for r in (3, 2)) if os.path.exists(p)), None)
+            if tpath is not None:
                 with open(tpath) as f:
                     tj = json.load(f)
                 if tj.get("graphs_per_step") == B:
-                    same = tj.get("source_digest") == source_digest()
+                    # the profile is stamped with the digest of the files named in its `digest_of` (r3: the Winograd translation
+                    # unit + the shared header; r2 profiles: every kernel source)
+                    same = tj.get("source_digest") == source_digest(tj.get("digest_of") or (None if "digest_of" not in tj else WINOGRAD_SOURCES))
                     line["roofline"]["traffic"] = round(tj["traffic_bytes_per_launch"])
                     line["roofline"]["committed_profile"] = {
-                        "file": "profiles/r2_pmc_wino43.json", "source_digest": tj.get("source_digest"),
+                        "file": "profiles/" + os.path.basename(tpath), "source_digest": tj.get("source_digest"),
                         "git_commit": tj.get("git_commit"), "matches_running_kernels": same,
                         "graphs_per_step": tj.get("graphs_per_step"),
                         "what": "traffic = 1024 * (2 * FETCH_SIZE + WRITE_SIZE) per launch of the main kernel, separate "

@@ -279,7 +279,8 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
 #define RPG_TUNE_WAVES8 11        /* 1: 8-wave workgroups (two waves per SIMD) for the 128x128 / 128x64 tiles of the f32 tile engine where
                                      the buffer-load path applies (default) | 0: always 4-wave workgroups */
 #define RPG_TUNE_FUSED_STEM 10    /* 1: one-kernel stem (conv7x7 + BN + ReLU + max-pool) where its operands are given (default) | 0: three kernels */
-#define RPG_TUNE_WINO_SPLIT 8     /* 1: split-K tail + fix-up for the 8-wave Winograd kernel (default) | 0: whole tiles only */
+#define RPG_TUNE_WINO_SPLIT 8     /* 1: split-K tail + fix-up for the 8-wave Winograd kernel (default) | 0: whole tiles only | n >= 2: as 1, and a part of a
+                                     tile gets at least n K steps in the one-workgroup-per-tile form (default 4; latency experiments at batch 1) */
 #define RPG_TUNE_FAST_LOADER 7    /* 1: buffer-load loaders + interleaved main loop where eligible (default) | 0: general loaders */
 #define RPG_TUNE_WINOGRAD 4       /* 0: always the direct kernel | 1: use u_wino43 where given, kernel by size (default) |
                                      2 / 3: as 1 but always the 4-wave single-image / the 8-wave Winograd kernel */
@@ -293,7 +294,9 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
                                      0: off | 1: by shape (default) | 10 + i: configuration i wherever eligible (experiments) */
 #define RPG_TUNE_BF16_PATCH 17    /* the patch kernel of the bf16 encoder's 3x3 / stride-1 convolutions (input patch resident in LDS, nine taps
                                      read it at shifted slots; Cin % 64 == 0): 0: off | 1: for more than 64 output channels on >= 8192
-                                     pixels (default) | 2: on any eligible size | 3: as 2 with the 256 x 128 tile for every width */
+                                     pixels (default) | 2: on any eligible size | 3: as 2 with the 256 x 128 tile for every width;
+                                     + 10: always three weight stages (without: four where the LDS allows -- the next step's weight fragments
+                                     are then read before the barrier) */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -18,6 +18,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "librelpose_gnn_hip.so")
 SOURCES = ("gemm_f32.hip", "winograd.hip", "stem.hip", "stem_bf16.hip", "conv_bf16.hip", "encoder_ops.hip", "gnn_ops.hip", "forward.hip", "timing.hip")
 ARCH = "gfx950"
+WINOGRAD_SOURCES = ("winograd.hip", "rpg_common.h")       # what the dominant (Winograd) kernel's code depends on
 
 
 def _hipcc() -> str:
@@ -27,13 +28,18 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
-def source_digest() -> str:
+def source_digest(names=None) -> str:
     """12 hex digits identifying the kernel sources (csrc/* + the C header): profiles/ artefacts are stamped with it so
-    that bench.py can tell whether a committed PMC profile was measured on the kernels it is running."""
+    that bench.py can tell whether a committed PMC profile was measured on the kernels it is running.  ``names``: only
+    those files of csrc/ (a profile of ONE kernel is stamped with the digest of the translation unit that holds it and the
+    shared header -- WINOGRAD_SOURCES for the dominant kernel -- so that work on other kernels does not orphan it)."""
     import hashlib
     h = hashlib.sha256()
-    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [
-        os.path.join(os.path.dirname(HERE), "include", "relpose_gnn_hip.h")]
+    if names is not None:
+        files = [os.path.join(CSRC, f) for f in sorted(names)]
+    else:
+        files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [
+            os.path.join(os.path.dirname(HERE), "include", "relpose_gnn_hip.h")]
     for f in files:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:

@@ -666,8 +666,14 @@ __device__ __forceinline__ void dma_piece16_raw(__amdgpu_buffer_rsrc_t rsrc, uns
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(lds_base + lds_byte_off), 16, voffset, soffset, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchArgs a, const __bf16* __restrict__ Wt, EpiB ep) {
+    // NS = weight stages.  3: the weights of step s + 2 are issued at step s and may be read from step s + 2's barrier on.
+    // 4: issued THREE steps ahead, waited for one step early -- at step s's barrier the weights of step s + 1 are already
+    // visible, so step s + 1's group-0 weight fragments are read behind step s's last MFMAs (like the A fragments, which come
+    // from the resident patch): nothing is left exposed behind a barrier but the barrier itself.  (Measured r3 with 3 stages:
+    // ~350 of a step's ~1400 cycles were the two weight reads + the wait in front of the first MFMA.)
+    static_assert(NS == 3 || NS == 4, "weight stages");
     constexpr int NW = WM * WN;
     static_assert(NW == 8, "8 waves");
     constexpr int FM = BM / WM / 32, FN = BN / WN / 32, NR = FM + FN;
@@ -696,7 +702,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x) + (size_t)n_first * img, 0,
                                                                           0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wt), 0, 0x7fffffff, 0x00020000);
-    const unsigned dummy_off = 2u * (unsigned)a.patch_bytes + 3u * BSTAGE;      // 1 KB nobody reads
+    const unsigned dummy_off = 2u * (unsigned)a.patch_bytes + (unsigned)NS * BSTAGE;      // 1 KB nobody reads
 
     // ---- patch pieces of this wave: piece q = wave + 8 t (t = 0 .. 7) covers 16-byte chunks 64 q .. 64 q + 63 of the buffer;
     // chunk ci = (slot ci >> 2, physical chunk ci & 3) <- logical chunk (ci & 3) ^ ((slot >> 2) & 3) of that pixel
@@ -781,22 +787,42 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
     // exposed.  Loads of the step: one patch piece of the next chunk (taps 0..7; tap 8: a dummy) in the first MFMA slot, the
     // weights of step s + 2 spread over the following slots.
     bf16x8 fr[2][NR];
-    auto read_a = [&](int set, int g, int i, int buf, int tap) {
-        const unsigned aoff = (unsigned)(buf * a.patch_bytes + (tap / 3) * P * 64);      // wave-uniform
+    // a3 is CARRIED through the chunk loop (it moves to the other patch buffer at every chunk end, see RPG_PATCH_CHUNK): written as
+    // a3 + buf * patch_bytes + kh * P * 64 with a loop-invariant a3, hipcc hoisted all 2 x 9 x FM x 2 sums out of the unrolled step
+    // loop and spilled them (100 VGPRs in the four-stage form)
+    auto read_a = [&](int set, int g, int i, int tap) {
+        const unsigned aoff = (unsigned)((tap / 3) * P * 64);                             // wave-uniform
         fr[set][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds_raw + (a3[i][tap % 3][g] + aoff)));
     };
-    auto read_b = [&](int set, int g, int j, int tap) {
-        fr[set][FM + j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds_raw + cb[g] + (tap % 3) * BSTAGE + j * 32 * 64));
+    auto flip_patch = [&](int buf) {                           // after a chunk on buffer `buf`: the next chunk reads the other one
+        const unsigned d = buf == 0 ? (unsigned)a.patch_bytes : 0u - (unsigned)a.patch_bytes;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) { a3[i][kw][0] += d; a3[i][kw][1] += d; }
     };
-    auto step = [&](int buf, int tap, int chunk) {
+    auto read_b = [&](int set, int g, int j, int stage) {
+        fr[set][FM + j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds_raw + cb[g] + stage * BSTAGE + j * 32 * 64));
+    };
+    // `sidx` = the step's index modulo NS (compile time: a chunk has 9 steps; with 3 stages 9 % 3 == 0 -> tap % 3, with 4 stages
+    // the caller unrolls 4 chunks = 36 steps = 0 mod 4)
+    auto step = [&](int buf, int tap, int chunk, int sbase, bool first, bool last) {
+        // stage of this step / of the steps it loads or prefetches for: compile-time with 3 stages (9 % 3 == 0), a wave-uniform
+        // runtime value with 4 (sbase = 9 * chunk mod 4; unrolling 4 chunks to make it a constant spilled 131 VGPRs)
+        auto stage_of = [&](int d) { return NS == 3 ? (tap + d) % 3 : (sbase + tap + d) & 3; };
+        const int sidx = 0;
+        (void)sidx;
         constexpr int G = FM * FN;
+        constexpr int AHEAD = NS - 1;                          // weights are issued this many steps ahead
         __builtin_amdgcn_sched_barrier(0);
         if (tap == 0) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i) read_a(0, 0, i, buf, tap);
+            for (int i = 0; i < FM; ++i) read_a(0, 0, i, tap);
         }
+        if (NS == 3 || first) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) read_b(0, 0, j, tap);
+            for (int j = 0; j < FN; ++j) read_b(0, 0, j, stage_of(0));
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ms = 0; ms < G; ++ms) {                      // k group 0
@@ -804,8 +830,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[0][i], fr[0][FM + j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int rk = ms * NR / G; rk < (ms + 1) * NR / G; ++rk) {
-                if (rk < FN) read_b(1, 1, rk, tap);
-                else read_a(1, 1, rk - FN, buf, tap);
+                if (rk < FN) read_b(1, 1, rk, stage_of(0));
+                else read_a(1, 1, rk - FN, tap);
             }
             if (ms == 0) {
                 if (tap < 8) issue_patch(tap, buf ^ 1, chunk + 1);
@@ -818,38 +844,54 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
             const int i = ms / FN, j = ms % FN;
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[1][i], fr[1][FM + j], acc[i][j], 0, 0, 0);
             if (ms == 0) {
-                if (tap + 2 < 9) issue_w((tap + 2) % 3, chunk, tap + 2);
-                else issue_w((tap + 2) % 3, chunk + 1, tap + 2 - 9);
+                if (tap + AHEAD < 9) issue_w(stage_of(AHEAD), chunk, tap + AHEAD);
+                else issue_w(stage_of(AHEAD), chunk + 1, tap + AHEAD - 9);
             }
             // next tap's group-0 A fragments (set 0 is free once group 0 has issued), early in the group: the wait in front of
             // the barrier must not find them still in flight
-            if (tap < 8 && ms < FM) read_a(0, 0, ms, buf, tap + 1);
+            if (tap < 8 && ms < FM) read_a(0, 0, ms, tap + 1);
+            // four stages: the next step's group-0 weight fragments too (its weights were waited for at THIS step's barrier)
+            if (NS == 4 && !last && ms >= FM && ms < FM + FN) read_b(0, 0, ms - FM, stage_of(1));
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    // ---- prologue: the first chunk's patch, the weights of steps 0 and 1 (the last NL loads are exactly what step 0's wait
-    // leaves outstanding)
+    // ---- prologue: the first chunk's patch, then the weights of the first NS - 1 steps; a dummy piece in front of each of the
+    // last NS - 2 weight sets makes the loads that a step's wait leaves outstanding exactly whole steps' worth (NL each)
 #pragma unroll
     for (int t = 0; t < 8; ++t) issue_patch(t, 0, 0);
     issue_w(0, 0, 0);
     issue_dummy();
     issue_w(1, 0, 1);
-#define RPG_PATCH_STEP(BUF, TAP, CHUNK)                                                  \
+    if (NS == 4) {
+        issue_dummy();
+        issue_w(2, 0, 2);
+    }
+    // step s: everything but the loads of the last NS - 3 + 1 steps has landed: with 3 stages the weights of step s (issued at
+    // s - 2; step s - 1's loads may be in flight), with 4 stages the weights of step s + 1 (issued at s - 2) as well
+#define RPG_PATCH_STEP(BUF, TAP, CHUNK, SIDX, FIRST, LAST)                                \
     do {                                                                                 \
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL) : "memory");              \
         __builtin_amdgcn_s_barrier();                                                    \
         asm volatile("" ::: "memory");                                                   \
-        step(BUF, TAP, CHUNK);                                                           \
+        step(BUF, TAP, CHUNK, SIDX, FIRST, LAST);                                        \
+    } while (0)
+#define RPG_PATCH_CHUNK(BUF, CHUNK, S0)                                                                                  \
+    do {                                                                                                                 \
+        const bool f0 = (CHUNK) == 0, l8 = (CHUNK) + 1 == NC;                                                            \
+        const int sb = (S0);                                                                                             \
+        RPG_PATCH_STEP(BUF, 0, CHUNK, sb, f0, false); RPG_PATCH_STEP(BUF, 1, CHUNK, sb, false, false);                   \
+        RPG_PATCH_STEP(BUF, 2, CHUNK, sb, false, false); RPG_PATCH_STEP(BUF, 3, CHUNK, sb, false, false);                \
+        RPG_PATCH_STEP(BUF, 4, CHUNK, sb, false, false); RPG_PATCH_STEP(BUF, 5, CHUNK, sb, false, false);                \
+        RPG_PATCH_STEP(BUF, 6, CHUNK, sb, false, false); RPG_PATCH_STEP(BUF, 7, CHUNK, sb, false, false);                \
+        RPG_PATCH_STEP(BUF, 8, CHUNK, sb, false, l8);                                                                    \
+        flip_patch(BUF);                                                                                                 \
     } while (0)
     for (int cc = 0; cc < NC; cc += 2) {
-        RPG_PATCH_STEP(0, 0, cc); RPG_PATCH_STEP(0, 1, cc); RPG_PATCH_STEP(0, 2, cc);
-        RPG_PATCH_STEP(0, 3, cc); RPG_PATCH_STEP(0, 4, cc); RPG_PATCH_STEP(0, 5, cc);
-        RPG_PATCH_STEP(0, 6, cc); RPG_PATCH_STEP(0, 7, cc); RPG_PATCH_STEP(0, 8, cc);
-        RPG_PATCH_STEP(1, 0, cc + 1); RPG_PATCH_STEP(1, 1, cc + 1); RPG_PATCH_STEP(1, 2, cc + 1);
-        RPG_PATCH_STEP(1, 3, cc + 1); RPG_PATCH_STEP(1, 4, cc + 1); RPG_PATCH_STEP(1, 5, cc + 1);
-        RPG_PATCH_STEP(1, 6, cc + 1); RPG_PATCH_STEP(1, 7, cc + 1); RPG_PATCH_STEP(1, 8, cc + 1);
+        RPG_PATCH_CHUNK(0, cc, (9 * cc) & 3);
+        RPG_PATCH_CHUNK(1, cc + 1, (9 * cc + 9) & 3);
     }
+#undef RPG_PATCH_CHUNK
 #undef RPG_PATCH_STEP
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -909,10 +951,11 @@ void launch_dma(const ConvArgsB& a, const __bf16* w, int M, int N, int K, const 
     hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(64 * WM * WN), lds, s, a, w, M, N, K, ep, tn);
 }
 
+int g_bf16_stages = 4;   // weight stages of the patch kernel (experiments: 3 = never the prefetching form); RPG_TUNE_BF16_PATCH + 10
 int g_bf16_patch = 1;    // RPG_TUNE_BF16_PATCH: the patch kernel for 3x3 / stride-1 convolutions: 0 off | 1 by shape | 2 wherever eligible
 
 // The patch kernel, if the shape is eligible (3x3, stride 1, pad 1, Cin % 64 == 0, patch <= 64 pieces, 32-bit offsets, LDS fits)
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NS>
 bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, const EpiB& ep, hipStream_t s) {
     if (c.KH != 3 || c.KW != 3 || c.stride != 1 || c.pad != 1 || (c.Cin & 63) || c.img_elems) return false;
     const int H = c.H, W = c.W, HW = H * W;
@@ -924,11 +967,11 @@ bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, c
     a.PR = rows + 2 * (imgs - 1) + 2;
     a.patch_bytes = (a.PR * a.P * 64 + 1023) / 1024 * 1024;
     a.n_pieces = a.patch_bytes / 1024;
-    const int lds = 2 * a.patch_bytes + 3 * BN * 64 + 1024;
+    const int lds = 2 * a.patch_bytes + NS * BN * 64 + 1024;
     constexpr int slab = 8 * 32 * ((BN / WN / 32) * 32 + 4) * 4;
     if (a.n_pieces > 64 || lds > 160 * 1024 || lds < slab) return false;
     if ((long)(imgs + 1) * HW * c.Cin * 2 >= (1L << 31) || (long)N * 9 * c.Cin * 2 >= (1L << 31)) return false;
-    auto kern = conv3x3_bf16_patch_kernel<BM, BN, WM, WN>;
+    auto kern = conv3x3_bf16_patch_kernel<BM, BN, WM, WN, NS>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     static bool once[64] = {};
@@ -1046,7 +1089,7 @@ void bf16_set_bk(int bk) { g_bf16_bk = bk; }
 void bf16_set_fast(int on) { g_bf16_fast = on; }
 void bf16_set_tile(int t) { g_bf16_tile = t; }
 void bf16_set_dma(int v) { g_bf16_dma = v; }
-void bf16_set_patch(int v) { g_bf16_patch = v; }
+void bf16_set_patch(int v) { g_bf16_stages = v >= 10 ? 3 : 4; g_bf16_patch = v % 10; }
 void bf16_set_fused_stem(int on) { g_bf16_fused_stem = on; }
 
 // fp32 [rows][ld_src] (first `cols` columns) -> bf16 dst[rows][ld_dst] at column offset col_off (cols % 8 == 0)
@@ -1157,9 +1200,15 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
         // by 5-10 %; 256 x 256 tiles where they occupy at least three quarters of the CUs, else 256 x 128 (layer 4 at 256 images:
         // 98 vs 196 tiles, 98 vs 68 us); at 128 channels the DMA kernel's 256 x 128 / K-step-32 configuration is faster
         const long t256 = ((M + 255) / 256) * ((cout + 255) / 256);
-        if (g_bf16_patch == 3) done = launch_patch<256, 128, 4, 2>(a, wp, n, (int)M, cout, ep, s);
-        else if (cout > 128 && 4 * t256 >= 3L * num_cus()) done = launch_patch<256, 256, 2, 4>(a, wp, n, (int)M, cout, ep, s);
-        else if (cout > 128 || g_bf16_patch == 2) done = launch_patch<256, 128, 4, 2>(a, wp, n, (int)M, cout, ep, s);
+        // four weight stages (next step's weight fragments prefetched before the barrier) where the LDS allows, else three
+        if (g_bf16_patch == 3 || !(cout > 128 && 4 * t256 >= 3L * num_cus())) {
+            if (cout > 128 || g_bf16_patch >= 2)
+                done = (g_bf16_stages != 3 && launch_patch<256, 128, 4, 2, 4>(a, wp, n, (int)M, cout, ep, s)) ||
+                       launch_patch<256, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s);
+        } else {
+            done = (g_bf16_stages != 3 && launch_patch<256, 256, 2, 4, 4>(a, wp, n, (int)M, cout, ep, s)) ||
+                   launch_patch<256, 256, 2, 4, 3>(a, wp, n, (int)M, cout, ep, s);
+        }
     }
     if (done) {
     } else if (dma_cfg >= 0 && launch_dma_config(dma_cfg, a, wp, (int)M, cout, (int)K, ep, s)) {

@@ -1100,6 +1100,7 @@ __global__ __launch_bounds__(NT) void wino43_weights_kernel(const float* __restr
 }
 
 int g_wino_split = 1;                    // RPG_TUNE_WINO_SPLIT: split-K tail of the 8-wave kernel
+int g_wino_split_steps = 4;              // ... and the least number of K steps a part of a tile gets in the one-workgroup-per-tile form (values >= 2 of the same key)
 int g_wino = 1;                          // RPG_TUNE_WINOGRAD: 0 off | 1 auto | 2 / 3: always the 4-wave / 8-wave kernel
 int g_wino_persist = 1;                  // RPG_TUNE_WINO_PERSIST: the persistent 8-wave kernel when a launch has more tiles than CUs
 
@@ -1109,7 +1110,7 @@ namespace rpg {
 
 bool wino_enabled() { return g_wino != 0; }
 void wino_set(int on) { g_wino = on; }
-void wino_split_set(int on) { g_wino_split = on; }
+void wino_split_set(int v) { g_wino_split = v != 0; g_wino_split_steps = v >= 2 ? v : 4; }
 void wino_short_set(int) {}              // RPG_TUNE_WINO_SHORT: retired with the short-K kernel (accepted, ignored)
 void wino_persist_set(int on) { g_wino_persist = on; }      // 2: also for launches of at most one tile per CU
 
@@ -1201,7 +1202,7 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
         if (g_wino_split && tail > 0) {
             int parts = (int)(S / tail);
             if (parts > kpr) parts = kpr;               // a part is at least one channel block (3 K steps)
-            if (parts > nk / 4 && nk / 4 >= 2) parts = nk / 4;
+            if (parts > nk / g_wino_split_steps && nk / g_wino_split_steps >= 2) parts = nk / g_wino_split_steps;
             if (parts >= 2) {
                 sp.partial = stream_scratch(s, (size_t)tail * parts * (BMT8 * 4 * BN) * sizeof(float));
                 if (sp.partial) { sp.parts = parts; t_main = T - tail; sp.tile_base = (int)t_main; sp.n_split = (int)(tail * parts); }

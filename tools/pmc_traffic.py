@@ -63,9 +63,10 @@ if os.path.exists(mp):
                 "mfma_pass": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE "
                              "SQ_INSTS_VALU_MFMA_F32 (same command); busy = BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8)"})
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from relpose_gnn_amd.build import source_digest  # noqa: E402
+from relpose_gnn_amd.build import WINOGRAD_SOURCES, source_digest  # noqa: E402
 alg = wino_algorithmic_bytes(8 * graphs)
-res.update({"graphs_per_step": graphs, "images_per_launch": 8 * graphs, "source_digest": source_digest(), "git_commit": commit,
+res.update({"graphs_per_step": graphs, "images_per_launch": 8 * graphs, "source_digest": source_digest(WINOGRAD_SOURCES), "digest_of": list(WINOGRAD_SOURCES),
+            "git_commit": commit,
             "algorithmic_bytes_per_launch": round(alg), "traffic_over_algorithmic": round(res["traffic_bytes_per_launch"] / alg, 3)})
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

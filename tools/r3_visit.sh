@@ -43,6 +43,13 @@ for step in "$@"; do
       timeout 900 python tools/conv_bench.py --bf16 --nimg 256 --warm 2 --reps 7 --only "l1.c" --dma-sweep 5,11,12 >> "$OUT/wide_sweep.txt" 2>&1
       timeout 900 python tools/conv_bench.py --bf16 --nimg 256 --warm 2 --reps 7 --only "l2." --dma-sweep 7,10 >> "$OUT/wide_sweep.txt" 2>&1
       cat "$OUT/wide_sweep.txt";;
+    lat1)
+      for v in 1 6 8 12 16; do
+        echo "wino split min steps $v"; timeout 300 python bench.py --steps 40 --warmup 5 --cpu-baseline-seconds 0 --graphs 1 --streams 1 --no-kernel-timing --tune 8=$v 2>/dev/null | cut -c1-200
+      done
+      for st in 1 2 3 4; do
+        echo "bf16 streams $st"; timeout 300 python bench.py --steps 20 --warmup 5 --cpu-baseline-seconds 0 --graphs 64 --encoder-dtype bf16 --gnn-dtype bf16 --streams $st --no-kernel-timing 2>/dev/null | cut -c1-200
+      done;;
     patchsweep)
       timeout 900 python tools/conv_bench.py --bf16 --nimg 512 --warm 2 --reps 7 --only l --dma-sweep 0,5,7 > "$OUT/patch_sweep_512.txt" 2>&1; cat "$OUT/patch_sweep_512.txt"
       timeout 900 python tools/conv_bench.py --bf16 --nimg 256 --warm 2 --reps 7 --only l --dma-sweep 0,5,7 > "$OUT/patch_sweep_256.txt" 2>&1; cat "$OUT/patch_sweep_256.txt";;
