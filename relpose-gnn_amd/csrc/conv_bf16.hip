@@ -677,8 +677,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
     constexpr int NW = WM * WN;
     static_assert(NW == 8, "8 waves");
     constexpr int FM = BM / WM / 32, FN = BN / WN / 32, NR = FM + FN;
-    constexpr int JB = BN / 16 / NW;                          // weight pieces (16 rows x 64 B) per wave and step
-    static_assert(BN % (16 * NW) == 0, "weight pieces must divide over the waves");
+    // weight pieces (16 rows x 64 B) per wave and step; a 64-channel tile has only 4: the other waves issue a dummy piece (every
+    // wave must issue the same number of loads per step for the counted waits)
+    constexpr int NBP = BN / 16;
+    constexpr int JB = NBP >= NW ? NBP / NW : 1;
+    static_assert(NBP % NW == 0 || NBP < NW, "weight pieces must divide over the waves");
     constexpr int BSTAGE = BN * 64;                           // bytes per weight stage
     constexpr unsigned OOB = 0x80000000u;
     constexpr int NL = 1 + JB;                                // loads per wave and step
@@ -740,9 +743,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
     auto issue_w = [&](int stage, int chunk, int tap) {
         const bool live = chunk < NC;
 #pragma unroll
-        for (int j = 0; j < JB; ++j)
-            dma_piece16_raw(rsw, 2u * (unsigned)a.patch_bytes + (unsigned)(stage * BSTAGE + (wave + NW * j) * 1024), lds_raw,
-                            live ? woff[j] : OOB, (tap * a.Cin + chunk * 32) * 2);
+        for (int j = 0; j < JB; ++j) {
+            if (NBP < NW && wave >= NBP) issue_dummy();
+            else dma_piece16_raw(rsw, 2u * (unsigned)a.patch_bytes + (unsigned)(stage * BSTAGE + (wave + NW * j) * 1024), lds_raw,
+                                 live ? woff[j] : OOB, (tap * a.Cin + chunk * 32) * 2);
+        }
     };
 
     // ---- A fragment addresses: pixel m of lane (i, lane & 31) -> slot s0 = (v(m) - 1 - v0) * P + c; tap (kh, kw) reads slot
@@ -1200,14 +1205,24 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
         // by 5-10 %; 256 x 256 tiles where they occupy at least three quarters of the CUs, else 256 x 128 (layer 4 at 256 images:
         // 98 vs 196 tiles, 98 vs 68 us); at 128 channels the DMA kernel's 256 x 128 / K-step-32 configuration is faster
         const long t256 = ((M + 255) / 256) * ((cout + 255) / 256);
-        // four weight stages (next step's weight fragments prefetched before the barrier) where the LDS allows, else three
-        if (g_bf16_patch == 3 || !(cout > 128 && 4 * t256 >= 3L * num_cus())) {
-            if (cout > 128 || g_bf16_patch >= 2)
-                done = (g_bf16_stages != 3 && launch_patch<256, 128, 4, 2, 4>(a, wp, n, (int)M, cout, ep, s)) ||
-                       launch_patch<256, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s);
-        } else {
+        // Tile by output width (every variant has 128 x 64 or 64 x 64 wave tiles on 8 waves): 256 x 256 from 256 channels up where
+        // that fills three quarters of the CUs, else 256 x 128; 512 x 128 for 128 channels, 512 x 64 for 64 -- the narrow layers
+        // need the tall tile to put 8-16 MFMAs per wave between two barriers.  Four weight stages (next step's weight fragments
+        // read before the barrier) where the LDS allows and it measured faster, else three.
+        const bool big = M >= 65536 || g_bf16_patch >= 2;
+        if (g_bf16_patch == 3) {
+            done = launch_patch<256, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s);
+        } else if (cout > 128 && 4 * t256 >= 3L * num_cus()) {
             done = (g_bf16_stages != 3 && launch_patch<256, 256, 2, 4, 4>(a, wp, n, (int)M, cout, ep, s)) ||
                    launch_patch<256, 256, 2, 4, 3>(a, wp, n, (int)M, cout, ep, s);
+        } else if (cout > 128) {
+            done = launch_patch<256, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s);
+        } else if (cout > 64 && big) {
+            done = (g_bf16_stages != 3 && launch_patch<512, 128, 4, 2, 4>(a, wp, n, (int)M, cout, ep, s)) ||
+                   launch_patch<512, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s);
+        } else if (big) {
+            done = (g_bf16_stages != 3 && launch_patch<512, 64, 8, 1, 4>(a, wp, n, (int)M, cout, ep, s)) ||
+                   launch_patch<512, 64, 8, 1, 3>(a, wp, n, (int)M, cout, ep, s);
         }
     }
     if (done) {

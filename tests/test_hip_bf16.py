@@ -198,7 +198,7 @@ def test_conv_bf16_dma_configs(dev, cfg, n, h, w, cin, cout, k, stride, pad, res
     assert rel_err(y.float().cpu().permute(0, 3, 1, 2), ref) < (1e-4 if f32out else 1e-2)
 
 
-@pytest.mark.parametrize("mode", [2, 3], ids=["by_width", "tile256x128"])
+@pytest.mark.parametrize("mode", [2, 3, 12], ids=["by_width", "tile256x128", "by_width_3stages"])
 @pytest.mark.parametrize("n,h,w,cin,cout,res,relu", [
     (40, 56, 56, 64, 64, True, True),       # layer-1 shape: 10 patch rows of 64 slots, 2 chunks
     (24, 28, 28, 128, 128, True, True),     # layer-2 shape
@@ -208,10 +208,13 @@ def test_conv_bf16_dma_configs(dev, cfg, n, h, w, cin, cout, k, stride, pad, res
     (5, 8, 11, 64, 320, False, True),       # 256x341's last stage; N = 320: two channel tiles, the second ragged
     (2, 5, 3, 128, 128, True, True),        # tiny image: 3 of 16 slots per patch row used, the whole batch inside one tile
     (1, 64, 86, 64, 64, False, True),       # 256x341's first stage: 96 slots per row
+    (256, 14, 14, 256, 256, True, True),    # 196 tiles of 256 x 256: the wide tile (and its four-stage form) is dispatched
+    (300, 7, 7, 512, 512, False, True),     # 58 x 2 tiles of 256 x 256 is too few -> 256 x 128; 53-KB patches: three stages only
 ])
 def test_conv3x3_bf16_patch_kernel(dev, mode, n, h, w, cin, cout, res, relu):
     """The patch kernel of the bf16 encoder (3x3 / stride 1 / pad 1 with the input patch resident in LDS; RPG_TUNE_BF16_PATCH = 2:
-    every eligible size, tile by output width; 3: the 256 x 128 tile everywhere) against F.conv2d on the same bf16 inputs in fp32:
+    every eligible size, tile by output width -- 512 x 64, 512 x 128, 256 x 128, 256 x 256; 3: the 256 x 128 tile everywhere; 12:
+    as 2 but never the four-weight-stage form) against F.conv2d on the same bf16 inputs in fp32:
     tiles that span image rows and whole images (virtual zero rows), zero halo slots from out-of-range DMA lanes, ragged M / N,
     2 .. 16 channel chunks through the two patch buffers and three weight stages."""
     from relpose_gnn_amd import ops

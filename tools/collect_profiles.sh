@@ -16,7 +16,21 @@ P="$R/bench.py --steps 3 --warmup 1 --cpu-baseline-seconds 0 --streams 1 --no-ke
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o p -- python3 $P > "$OUT/pmc_fetch.log" 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o p -- python3 $P > "$OUT/pmc_write.log" 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_F32 --output-format csv -d "$OUT/pmc_mfma" -o p -- python3 $P > "$OUT/pmc_mfma.log" 2>&1
+# bf16 path (configs[2]: 64 graphs, bf16 encoder + bf16 GNN Linears): kernel trace + matrix-pipe / LDS / traffic counters
+BB="$R/bench.py --steps 5 --warmup 2 --cpu-baseline-seconds 0 --graphs 64 --encoder-dtype bf16 --gnn-dtype bf16"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_bf16_1stream" -o t -- python3 $BB --streams 1 > "$OUT/trace_bf16_1stream.log" 2>&1
+PB="$BB --steps 3 --warmup 1 --streams 1 --no-kernel-timing"
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d "$OUT/pmc_bf16_sq" -o p -- python3 $PB > "$OUT/pmc_bf16_sq.log" 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_BF16 --output-format csv -d "$OUT/pmc_bf16_mops" -o p -- python3 $PB > "$OUT/pmc_bf16_mops.log" 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_bf16_fetch" -o p -- python3 $PB > "$OUT/pmc_bf16_fetch.log" 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_bf16_write" -o p -- python3 $PB > "$OUT/pmc_bf16_write.log" 2>&1
 cd "$R"
+for k in conv3x3_bf16_patch conv_bf16_dma stem_pool_bf16; do
+  python3 tools/pmc_summary.py "$OUT" $k >> "$OUT/pmc_bf16_summary.txt" 2>&1
+done
+f=$(ls "$OUT"/trace_bf16_1stream/*kernel_stats.csv 2>/dev/null | head -1)
+[ -n "$f" ] && python3 tools/rocprof_summary.py "$f" "$OUT/kernel_stats_bf16_1stream.txt" > /dev/null
+rm -rf "$OUT"/pmc_bf16_sq "$OUT"/pmc_bf16_mops "$OUT"/pmc_bf16_fetch "$OUT"/pmc_bf16_write "$OUT"/trace_bf16_1stream/*kernel_trace.csv
 python3 tools/pmc_traffic.py "$OUT" "wino43_conv8" "$OUT/pmc_wino43.json" 32 > "$OUT/pmc_wino43.txt" 2>&1
 python3 tools/pmc_summary.py "$OUT" wino43 > "$OUT/pmc_wino43_summary.txt" 2>&1
 python3 tools/pmc_summary.py "$OUT" stem_pool > "$OUT/pmc_stem_summary.txt" 2>&1
