@@ -1220,7 +1220,10 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
         } else if (cout > 64 && big) {
             done = (g_bf16_stages != 3 && launch_patch<512, 128, 4, 2, 4>(a, wp, n, (int)M, cout, ep, s)) ||
                    launch_patch<512, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s);
-        } else if (big) {
+        } else if (g_bf16_patch >= 2) {
+            // 64 output channels (layer 1): measured 232-245 us at 512 images against 205-222 us for the im2col DMA kernel with two
+            // 80-KB workgroups per CU (configuration 5) -- a 512 x 64 tile is 18 short steps behind a 61-KB patch, and with one
+            // workgroup per CU nothing overlaps its prologue / epilogue.  Kept for the tests and experiments (mode 2) only.
             done = (g_bf16_stages != 3 && launch_patch<512, 64, 8, 1, 4>(a, wp, n, (int)M, cout, ep, s)) ||
                    launch_patch<512, 64, 8, 1, 3>(a, wp, n, (int)M, cout, ep, s);
         }
