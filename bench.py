@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=180.0,
                     help="budget of the whole CPU baseline leg (three thread counts x B = 1/8/32); 0 disables it")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-graph latency leg (profiling runs: keeps its launches out of the trace)")
     ap.add_argument("--launcher", action="store_true",
                     help="start the rank(s) through this script's own torch.distributed.run command line even for --gpus 1: the "
                          "launcher, RCCL initialisation and the per-step all-gather then run on a one-GPU box too")
@@ -311,7 +312,7 @@ def main():
     # call, host-synchronised after every call (median of 40) and streamed (40 calls, one synchronisation).  Reported next
     # to `value`, never as `value`.
     lat1 = None
-    if rank == 0 and args.encoder_dtype == "f32" and not args.no_kernel_timing:
+    if rank == 0 and args.encoder_dtype == "f32" and not args.no_kernel_timing and not args.no_latency:
         d1 = fc_batch(x[:NODES], NODES)
         for _ in range(5):
             model(d1)

@@ -54,6 +54,9 @@ struct StemBArgs {
     int N, H, W, Hc, Wc, Hp, Wp;
     int TWp, tiles_x, tiles_y, RW, nfrag, total_tiles;
     int nbx, nblk, ncl;
+    // fragments of every wave in processing order (0xFF = none): balanced on the host -- a leftover fragment (table-driven pooling,
+    // up to 128 LDS atomics) costs about 2.5 block fragments, and dealt round-robin one wave ended up with 4.5 units against 2.7
+    unsigned char wl[8][8];
 };
 
 // byte offset of patch row (c, kh) relative to a pixel's first row
@@ -164,7 +167,9 @@ __global__ __launch_bounds__(SB_NT) void stem_pool_bf16_kernel(StemBArgs a) {
         __syncthreads();
         // ---- phase 2: 32 convolution pixels x 64 channels per fragment, fragments dealt round-robin to the waves (block
         // fragments = 4 rows x 8 columns, leftover pixels 32 in a row: stem.hip)
-        for (int f = wave; f < a.nfrag; f += SB_NT / 64) {
+        for (int fi = 0; fi < 8; ++fi) {
+            const int f = a.wl[wave][fi];
+            if (f == 0xFF) break;
             const bool blk = f < a.nblk;
             int oy, ox, by = 0, bx = 0;
             if (blk) {
@@ -308,6 +313,21 @@ int launch_stem_pool_bf16(const float* x_nchw, const void* wpack, const float* s
     const long total = (long)n * a.tiles_y * a.tiles_x;
     if (total >= (1L << 31) || (long)n * 3 * h * w >= (1L << 40)) return RPG_ERR_BAD_ARG;
     a.total_tiles = (int)total;
+    {   // longest-processing-time-first: leftover fragments (cost 5) first, then block fragments (cost 2), each to the least loaded wave
+        if (a.nfrag > 64) return RPG_ERR_BAD_ARG;
+        int load[8] = {0}, cnt[8] = {0};
+        for (int w8 = 0; w8 < 8; ++w8)
+            for (int k = 0; k < 8; ++k) a.wl[w8][k] = 0xFF;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int f = pass == 0 ? a.nblk : 0; f < (pass == 0 ? a.nfrag : a.nblk); ++f) {
+                int best = 0;
+                for (int w8 = 1; w8 < 8; ++w8)
+                    if (load[w8] < load[best]) best = w8;
+                if (cnt[best] >= 8) return RPG_ERR_BAD_ARG;
+                a.wl[best][cnt[best]++] = (unsigned char)f;
+                load[best] += pass == 0 ? 5 : 2;
+            }
+    }
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     static bool attr[64] = {};

@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-B="$R/bench.py --steps 5 --warmup 2 --cpu-baseline-seconds 0"
+B="$R/bench.py --steps 5 --warmup 2 --cpu-baseline-seconds 0 --no-latency"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -o t -- python3 $B > "$OUT/trace_default.log" 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_1stream" -o t -- python3 $B --streams 1 > "$OUT/trace_1stream.log" 2>&1
 P="$R/bench.py --steps 3 --warmup 1 --cpu-baseline-seconds 0 --streams 1 --no-kernel-timing"

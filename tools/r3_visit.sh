@@ -37,6 +37,10 @@ for step in "$@"; do
     dmasweep)
       timeout 900 python tools/conv_bench.py --bf16 --nimg 512 --warm 2 --reps 7 --only l --dma-sweep 0,1,2,3,4,5,6,7,8,9 > "$OUT/dma_sweep_512.txt" 2>&1; cat "$OUT/dma_sweep_512.txt"
       timeout 900 python tools/conv_bench.py --bf16 --nimg 256 --warm 2 --reps 7 --only l --dma-sweep 0,1,3,4,5,7,9 > "$OUT/dma_sweep_256.txt" 2>&1; cat "$OUT/dma_sweep_256.txt";;
+    l1sweep)
+      timeout 900 python tools/conv_bench.py --bf16 --nimg 512 --warm 2 --reps 7 --only "l1.c" --dma-sweep 5,9,10,11,12,13 > "$OUT/l1_sweep.txt" 2>&1
+      timeout 900 python tools/conv_bench.py --bf16 --nimg 256 --warm 2 --reps 7 --only "l1.c" --dma-sweep 5,9,10,11,12,13 >> "$OUT/l1_sweep.txt" 2>&1
+      cat "$OUT/l1_sweep.txt";;
     widesweep)
       timeout 900 python tools/conv_bench.py --bf16 --nimg 512 --warm 2 --reps 7 --only "l1.c" --dma-sweep 5,11,12 > "$OUT/wide_sweep.txt" 2>&1
       timeout 900 python tools/conv_bench.py --bf16 --nimg 512 --warm 2 --reps 7 --only "l2." --dma-sweep 7,10 >> "$OUT/wide_sweep.txt" 2>&1
