@@ -1004,10 +1004,6 @@ bool launch_dma_config(int cfg, const ConvArgsB& a, const __bf16* w, int M, int 
         case 7: if (!k32) return false; launch_dma<256, 128, 4, 2, 32, 3>(a, w, M, N, K, ep, s); return true;   // 72 KB: 2 workgroups / CU
         case 8: if (!k64) return false; launch_dma<128, 128, 2, 2, 64, 3>(a, w, M, N, K, ep, s); return true;   // 96 KB
         case 9: if (!k32) return false; launch_dma<128, 64, 2, 2, 32, 4>(a, w, M, N, K, ep, s); return true;    // 48 KB: 3 workgroups / CU
-        case 10: if (!k32) return false; launch_dma<256, 64, 4, 1, 32, 4>(a, w, M, N, K, ep, s); return true;   // 80 KB, 4 waves, wave 64 x 64, 3 steps ahead
-        case 11: if (!k64) return false; launch_dma<256, 64, 4, 1, 64, 2>(a, w, M, N, K, ep, s); return true;   // 80 KB, 4 waves, wave 64 x 64
-        case 12: if (!k32) return false; launch_dma<256, 64, 4, 1, 32, 3>(a, w, M, N, K, ep, s); return true;   // 60 KB, 4 waves: still 2 workgroups / CU
-        case 13: if (!k32) return false; launch_dma<128, 64, 2, 1, 32, 4>(a, w, M, N, K, ep, s); return true;   // 48 KB, 2 waves, 3 workgroups / CU
         // (measured and removed, r3: 512 x 128 / 1024 x 64 / 512 x 64 tiles with 128 x 64 wave tiles for the narrow layers 1-2 --
         // 280-290 us on layer 1 against 205 us for configuration 5, 190 us on layer 2 against 160 us for configuration 7: fewer,
         // fatter workgroups lose more to the one-workgroup-per-CU prologue / epilogue than the wave tile wins in LDS reads)
