@@ -96,6 +96,13 @@ def main():
         r = torch.randn(n, ho, wo, cout, device=dev) if res else None
         if args.bf16:
             if name == "stem":
+                from importlib import import_module
+                P = import_module("relpose-gnn_amd.params")
+                xin = torch.randn(n, 3, h, w, device=dev)
+                wp = P.pack_stem_bf16(torch.randn(64, 3, 7, 7) * 0.1).to(dev)
+                med, best = timeit(lambda: ops.stem_conv_bn_relu_maxpool_bf16(xin, wp, sc, sh), args.reps)
+                fl = 2.0 * n * ho * wo * cout * 147
+                print(f"fused bf16 stem  images={n}  {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF (best {fl/best/1e9:6.1f})", flush=True)
                 continue
             xb, wb = x.bfloat16(), wt.bfloat16()
             rb = None if r is None else r.bfloat16()

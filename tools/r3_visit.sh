@@ -68,6 +68,13 @@ for step in "$@"; do
       done
       timeout 600 python tools/eval_stream.py --graphs 4000 --shape 256x341 --input host --encoder-dtype bf16 --gnn-dtype bf16 >> "$OUT/eval_stream.jsonl" 2>> "$OUT/eval_stream.err"
       cat "$OUT/eval_stream.jsonl";;
+    stemtest)
+      timeout 900 python -m pytest tests/test_hip_bf16.py -q -m gpu -k "stem" > "$OUT/pytest_stem.log" 2>&1; echo "pytest rc=$?"; tail -15 "$OUT/pytest_stem.log"
+      timeout 600 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --reps 10 --only stem > "$OUT/stem_512.txt" 2>&1; cat "$OUT/stem_512.txt";;
+    stemablate)
+      for d in ${STEM_DBG:-0 8 4 12 2 6 14 46 1 16 17 63}; do
+        echo "dbg $d"; RPG_STEM_DBG=$d timeout 600 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --reps 10 --only stem 2>&1 | grep fused
+      done | tee "$OUT/stem_ablate.txt";;
     *) echo "unknown step $step";;
   esac
 done
