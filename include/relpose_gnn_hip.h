@@ -297,6 +297,10 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
                                      pixels (default) | 2: on any eligible size | 3: as 2 with the 256 x 128 tile for every width;
                                      + 10: always three weight stages (without: four where the LDS allows -- the next step's weight fragments
                                      are then read before the barrier) */
+#define RPG_TUNE_BF16_WS64 18     /* the weights-stationary kernel of the bf16 encoder's 64 -> 64 channel 3x3 / stride-1 convolutions (ResNet
+                                     layer 1; all 73 KB of weights in a wave's registers, 4 waves per CU, input patch in LDS) -- an experiment that
+                                     measured no faster than the kernels it would replace: 0: off (default) | 1: on >= 8192 pixels,
+                                     384-pixel tiles | 2: 256-pixel tiles */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

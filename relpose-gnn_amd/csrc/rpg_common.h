@@ -81,6 +81,7 @@ void bf16_set_tile(int t);
 void bf16_set_dma(int v);
 void bf16_set_patch(int v);
 void bf16_set_fused_stem(int on);
+void bf16_set_ws64(int v);
 bool stem_pool_bf16_supported(int h, int w, int cout);
 int launch_stem_pool_bf16(const float* x_nchw, const void* wpack, const float* scale, const float* shift, void* out, int n, int h,
                           int w, hipStream_t s);

@@ -84,6 +84,8 @@ def main():
     ops.set_tuning(ops.TUNE_TILE, args.tile)
     ops.set_tuning(ops.TUNE_STREAMK, args.sk)
     ops.set_tuning(ops.TUNE_WINOGRAD, args.wino)
+    if os.environ.get("RPG_WS64"):
+        ops.set_tuning(ops.TUNE_BF16_WS64, int(os.environ["RPG_WS64"]))
     print(f"# bk={args.bk} epi={args.epi} tile={args.tile} streamk={args.sk}", flush=True)
     for name, n, h, w, cin, cout, k, s, p, res in SHAPES:
         if args.only and args.only not in name:

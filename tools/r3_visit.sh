@@ -75,6 +75,9 @@ for step in "$@"; do
       for d in ${STEM_DBG:-0 8 4 12 2 6 14 46 1 16 17 63}; do
         echo "dbg $d"; RPG_STEM_DBG=$d timeout 600 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --reps 10 --only stem 2>&1 | grep fused
       done | tee "$OUT/stem_ablate.txt";;
+    ws64)
+      timeout 900 python -m pytest tests/test_hip_bf16.py -q -m gpu -x -k "weights_stationary" > "$OUT/pytest_ws64.log" 2>&1; echo "pytest rc=$?"; tail -15 "$OUT/pytest_ws64.log"
+      for m in 0 1 2; do echo "ws64 mode $m"; RPG_WS64=$m timeout 600 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --reps 10 --only l1.c 2>&1 | grep conv; done | tee "$OUT/ws64_512.txt";;
     *) echo "unknown step $step";;
   esac
 done
