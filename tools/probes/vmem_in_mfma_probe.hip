@@ -45,6 +45,25 @@ __global__ __launch_bounds__(1024) void probe(const uint4* __restrict__ src, uin
     if (lane == 0) atomicAdd((unsigned long long*)cyc, (unsigned long long)(t1 - t0));
 }
 
+// the fp32 matrix pipe alone (v_mfma_f32_32x32x2f32, the Winograd kernel's instruction): what does it sustain?
+typedef float f32x16b __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(1024) void probe_f32(const float* __restrict__ src, float* __restrict__ dst, int steps) {
+    const int lane = threadIdx.x & 63;
+    f32x16b acc[6];
+    for (int i = 0; i < 6; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const float a = src[lane], b = src[64 + lane];
+    for (int s = 0; s < steps; ++s) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float sum = 0.f;
+    for (int i = 0; i < 6; ++i) sum += acc[i][0];
+    if (sum == 12345.f) dst[0] = sum;
+}
+
 int main(int argc, char** argv) {
     const int steps = argc > 1 ? atoi(argv[1]) : 512;
     int dev = 0; hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev);
@@ -66,6 +85,18 @@ int main(int argc, char** argv) {
             if (rep == 1)
                 printf("MFMA only, %2d waves per CU: %.1f us -> %.3f PFLOP/s (32x32x16 bf16, 6 independent accumulators per wave)\n", nw, ms * 1e3,
                        (double)cus * nw * steps * 6 * 32768.0 / (ms * 1e-3) / 1e15);
+        }
+    }
+    for (int nw : {4, 8, 16}) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0);
+            hipLaunchKernelGGL(probe_f32, dim3(cus), dim3(64 * nw), 0, 0, (const float*)src, (float*)dst, steps * 2);
+            (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+            float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+            if (rep == 1)
+                printf("fp32 MFMA only, %2d waves per CU: %.1f us -> %.1f TFLOP/s (32x32x2 f32, 6 independent accumulators per wave; data sheet 157.3)\n", nw,
+                       ms * 1e3, (double)cus * nw * steps * 2 * 6 * 4096.0 / (ms * 1e-3) / 1e12);
         }
     }
     for (int mode : {0, 1, 2, 3, 4, 0}) {
