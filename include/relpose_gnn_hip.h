@@ -280,7 +280,7 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
                                      the buffer-load path applies (default) | 0: always 4-wave workgroups */
 #define RPG_TUNE_FUSED_STEM 10    /* 1: one-kernel stem (conv7x7 + BN + ReLU + max-pool) where its operands are given (default) | 0: three kernels */
 #define RPG_TUNE_WINO_SPLIT 8     /* 1: split-K tail + fix-up for the 8-wave Winograd kernel (default) | 0: whole tiles only | n >= 2: as 1, and a part of a
-                                     tile gets at least n K steps in the one-workgroup-per-tile form (default 4; latency experiments at batch 1) */
+                                     tile gets at least n K steps in the one-workgroup-per-tile form (default 3: one 8-node graph 1.50 ms per forward, 1.63 with 4) */
 #define RPG_TUNE_FAST_LOADER 7    /* 1: buffer-load loaders + interleaved main loop where eligible (default) | 0: general loaders */
 #define RPG_TUNE_WINOGRAD 4       /* 0: always the direct kernel | 1: use u_wino43 where given, kernel by size (default) |
                                      2 / 3: as 1 but always the 4-wave single-image / the 8-wave Winograd kernel */

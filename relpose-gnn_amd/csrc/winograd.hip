@@ -1100,7 +1100,9 @@ __global__ __launch_bounds__(NT) void wino43_weights_kernel(const float* __restr
 }
 
 int g_wino_split = 1;                    // RPG_TUNE_WINO_SPLIT: split-K tail of the 8-wave kernel
-int g_wino_split_steps = 4;              // ... and the least number of K steps a part of a tile gets in the one-workgroup-per-tile form (values >= 2 of the same key)
+int g_wino_split_steps = 3;              // ... and the least number of K steps a part of a tile gets in the one-workgroup-per-tile form (values >= 2 of the same key;
+                                         // one 8-node graph, r3: 4 -> 1.63 ms per forward, 3 or 2 -> 1.50; 6 -> 1.61; the benched 32-graph launches do not get here:
+                                         // their part count is bound by CUs / tail tiles)
 int g_wino = 1;                          // RPG_TUNE_WINOGRAD: 0 off | 1 auto | 2 / 3: always the 4-wave / 8-wave kernel
 int g_wino_persist = 1;                  // RPG_TUNE_WINO_PERSIST: the persistent 8-wave kernel when a launch has more tiles than CUs
 
@@ -1110,7 +1112,7 @@ namespace rpg {
 
 bool wino_enabled() { return g_wino != 0; }
 void wino_set(int on) { g_wino = on; }
-void wino_split_set(int v) { g_wino_split = v != 0; g_wino_split_steps = v >= 2 ? v : 4; }
+void wino_split_set(int v) { g_wino_split = v != 0; g_wino_split_steps = v >= 2 ? v : 3; }
 void wino_short_set(int) {}              // RPG_TUNE_WINO_SHORT: retired with the short-K kernel (accepted, ignored)
 void wino_persist_set(int on) { g_wino_persist = on; }      // 2: also for launches of at most one tile per CU
 
@@ -1158,7 +1160,7 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
     if (fits8 && (g_wino == 3 || (g_wino == 1 && tm8 * tn >= 8))) {
         // large problems (or RPG_TUNE_WINOGRAD = 3): 8 waves on 128 tiles, double-buffered, one workgroup per CU.
         // The tiles beyond the last full round of CUs would cost a whole extra round (784 tiles on 256 CUs: a 4th
-        // round for 2 % of the work): they are cut along K into floor(CUs / tail) parts (>= 4 K steps each) whose partial
+        // round for 2 % of the work): they are cut along K into floor(CUs / tail) parts (>= g_wino_split_steps K steps each) whose partial
         // tiles a small fix-up kernel adds in k order.
         static bool attr8[64] = {};
         if (!attr8[dev]) {
