@@ -301,6 +301,7 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
                                      layer 1; all 73 KB of weights in a wave's registers, 4 waves per CU, input patch in LDS) -- an experiment that
                                      measured no faster than the kernels it would replace: 0: off (default) | 1: on >= 8192 pixels,
                                      384-pixel tiles | 2: 256-pixel tiles */
+#define RPG_TUNE_SK_MIN_ITS 19    /* least K steps a stream-K workgroup of the fp32 GEMM engine gets (default 8) */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus
