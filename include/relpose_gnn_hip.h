@@ -125,6 +125,11 @@ int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors, const int
  *                                (relpose-gnn_amd/params.py pack_stem_bf16 builds it).                                   */
 int rpg_stem_conv7x7s2_bn_relu_maxpool_bf16(const float* x_nchw, const void* wpack_bf16, const float* scale, const float* shift,
                                             void* y_nhwc_bf16, int n, int h, int w, void* stream);
+/* ... and on node images that are ALREADY bf16 [n][3][h][w] (the reference's fp32 `data.x`, posenet.py:1034-1035, rounded to bf16
+ * on the host so that the host-to-device copy is half the size): the kernel above rounds its fp32 input to bf16 first thing, so the
+ * result is bit-identical. */
+int rpg_stem_conv7x7s2_bn_relu_maxpool_bf16_xbf16(const void* x_nchw_bf16, const void* wpack_bf16, const float* scale, const float* shift,
+                                                  void* y_nhwc_bf16, int n, int h, int w, void* stream);
 int rpg_conv2d_bn_act_nhwc_bf16(const void* x, const void* w_ohwi, const float* scale, const float* shift,
                                 const void* residual, void* y, int n, int h, int w, int cin, int cout, int kh, int kw,
                                 int stride, int pad, int relu, int out_f32, void* stream);
@@ -132,6 +137,11 @@ size_t rpg_resnet_bf16_workspace_bytes(int n, int h, int w, const int* planes);
 int rpg_resnet_forward_bf16(const void* const* tensors, int n_tensors, const int* blocks, const int* planes, int feat_dim,
                             const float* x_nchw, int n, int h, int w, float* feat, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* the same forward on bf16 node images (see rpg_stem_conv7x7s2_bn_relu_maxpool_bf16_xbf16); needs the fused stem's wpack as the
+ * optional last tensor (RPG_ERR_BAD_ARG without it: the three-kernel stem reads fp32 only) */
+int rpg_resnet_forward_bf16_xbf16(const void* const* tensors, int n_tensors, const int* blocks, const int* planes, int feat_dim,
+                                  const void* x_nchw_bf16, int n, int h, int w, float* feat, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------- */
 /* GNN primitives                                                                                */
@@ -301,6 +311,10 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
                                      layer 1; all 73 KB of weights in a wave's registers, 4 waves per CU, input patch in LDS) -- an experiment that
                                      measured no faster than the kernels it would replace: 0: off (default) | 1: on >= 8192 pixels,
                                      384-pixel tiles | 2: 256-pixel tiles */
+/* HOST: fp32 -> bf16 (round to nearest even, NaN -> quiet NaN: what the device's conversion and torch's .bfloat16() do) of a
+ * contiguous host array; thread-safe, called by evaluate_stream's staging threads for the bf16 encoder's node images. */
+int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
+
 #define RPG_TUNE_SK_MIN_ITS 19    /* least K steps a stream-K workgroup of the fp32 GEMM engine gets (default 8) */
 int rpg_set_tuning(int key, int value);
 

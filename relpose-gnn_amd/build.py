@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "librelpose_gnn_hip.so")
-SOURCES = ("gemm_f32.hip", "winograd.hip", "stem.hip", "stem_bf16.hip", "conv_bf16.hip", "encoder_ops.hip", "gnn_ops.hip", "forward.hip", "timing.hip")
+SOURCES = ("gemm_f32.hip", "winograd.hip", "stem.hip", "stem_bf16.hip", "conv_bf16.hip", "encoder_ops.hip", "gnn_ops.hip", "forward.hip", "timing.hip", "host_ops.hip")
 ARCH = "gfx950"
 WINOGRAD_SOURCES = ("winograd.hip", "rpg_common.h")       # what the dominant (Winograd) kernel's code depends on
 

@@ -1582,9 +1582,10 @@ extern "C" size_t rpg_resnet_bf16_workspace_bytes(int n, int h, int w, const int
 }
 
 // tensors: per conv {w_ohwi bf16, scale f32, shift f32} (stem Cin padded to 8), then fc weight bf16 [feat][512], bias f32.
-extern "C" int rpg_resnet_forward_bf16(const void* const* tensors, int n_tensors, const int* blocks, const int* planes,
-                                       int feat_dim, const float* x_nchw, int n, int h, int w, float* feat, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
+static int resnet_forward_bf16_impl(const void* const* tensors, int n_tensors, const int* blocks, const int* planes, int feat_dim,
+                                   const void* x_nchw_any, int x_is_bf16, int n, int h, int w, float* feat, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    const float* x_nchw = reinterpret_cast<const float*>(x_nchw_any);       // (only read as fp32 when !x_is_bf16)
     if (!tensors || !blocks || !planes || !x_nchw || !feat || !workspace || n <= 0 || h <= 0 || w <= 0 || feat_dim <= 0 ||
         (feat_dim & 3))
         return RPG_ERR_BAD_ARG;
@@ -1630,9 +1631,11 @@ extern "C" int rpg_resnet_forward_bf16(const void* const* tensors, int n_tensors
     int rc, ti = 0;
     if (stem_pack && g_bf16_fused_stem && rpg::stem_pool_bf16_supported(h, w, planes[0])) {
         // fp32 NCHW -> conv7x7/2 + BN + ReLU + maxpool3x3/2 -> pooled bf16 NHWC, one kernel
-        if ((rc = rpg::launch_stem_pool_bf16(x_nchw, stem_pack, (const float*)tensors[1], (const float*)tensors[2], buf[0], n, h, w,
-                                             s)) != RPG_OK)
+        if ((rc = rpg::launch_stem_pool_bf16(x_nchw_any, x_is_bf16, stem_pack, (const float*)tensors[1], (const float*)tensors[2], buf[0],
+                                             n, h, w, s)) != RPG_OK)
             return rc;
+    } else if (x_is_bf16) {
+        return RPG_ERR_BAD_ARG;                 // the three-kernel stem reads fp32 only: convert the input (or ship the stem pack)
     } else {
         const long npix = (long)n * h * w;
         hipLaunchKernelGGL(nchw3_to_nhwc8_bf16_kernel, dim3(capped_grid(npix)), dim3(NT), 0, s, x_nchw,
@@ -1685,6 +1688,22 @@ extern "C" int rpg_resnet_forward_bf16(const void* const* tensors, int n_tensors
     // fc as a 1x1 convolution on a 1x1 image: [n][1][1][cin] x [feat][1][1][cin], bias in `shift`, fp32 output
     return rpg::launch_conv_bf16(pool, tensors[ti], nullptr, (const float*)tensors[ti + 1], nullptr, feat, n, 1, 1, cin,
                                  feat_dim, 1, 1, 1, 0, 0, 1, s);
+}
+
+extern "C" int rpg_resnet_forward_bf16(const void* const* tensors, int n_tensors, const int* blocks, const int* planes,
+                                       int feat_dim, const float* x_nchw, int n, int h, int w, float* feat, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    return resnet_forward_bf16_impl(tensors, n_tensors, blocks, planes, feat_dim, x_nchw, 0, n, h, w, feat, workspace, workspace_bytes,
+                                    stream);
+}
+
+// the same forward on node images that are already bf16 (rounded from fp32 on the host, so that the H2D copy is half the size);
+// needs the fused stem's operands as the optional last tensor, RPG_ERR_BAD_ARG otherwise
+extern "C" int rpg_resnet_forward_bf16_xbf16(const void* const* tensors, int n_tensors, const int* blocks, const int* planes,
+                                             int feat_dim, const void* x_nchw_bf16, int n, int h, int w, float* feat, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+    return resnet_forward_bf16_impl(tensors, n_tensors, blocks, planes, feat_dim, x_nchw_bf16, 1, n, h, w, feat, workspace,
+                                    workspace_bytes, stream);
 }
 
 extern "C" int rpg_f32_to_bf16(const float* src, int ld_src, void* dst, int ld_dst, int col_off, long rows, int cols,

@@ -83,7 +83,7 @@ void bf16_set_patch(int v);
 void bf16_set_fused_stem(int on);
 void bf16_set_ws64(int v);
 bool stem_pool_bf16_supported(int h, int w, int cout);
-int launch_stem_pool_bf16(const float* x_nchw, const void* wpack, const float* scale, const float* shift, void* out, int n, int h,
+int launch_stem_pool_bf16(const void* x_nchw, int x_is_bf16, const void* wpack, const float* scale, const float* shift, void* out, int n, int h,
                           int w, hipStream_t s);
 int launch_f32_to_bf16(const float* src, int ld_src, void* dst, int ld_dst, int col_off, long rows, int cols, hipStream_t s);
 int launch_linear_bf16(const void* a, const void* w, const float* bias, const float* res, const int64_t* res_idx,

@@ -57,7 +57,7 @@ constexpr int KS = 11;                     // MFMAs per fragment and 32 channels
 constexpr int NF = 2;                      // 32-channel fragments
 
 struct StemBArgs {
-    const float* x;        // [N][3][H][W] fp32
+    const void* x;         // [N][3][H][W] fp32, or bf16 (kernel template parameter: the values a host-side rounding of the fp32 input gives)
     const uint4* wpack;    // [KS][NF][64] x 8 bf16: lane l of fragment nf, step s: W[ch = 32 nf + (l & 31)][(c, kh) = row 2s + (l >> 5)][kw 0..7]
     const float* scale;    // [64] folded BatchNorm scale
     const float* shift;    // [64] folded BatchNorm shift
@@ -70,6 +70,7 @@ struct StemBArgs {
 // byte offset of patch row (c, kh) relative to a pixel's first row
 __host__ __device__ constexpr int krow_off(int idx) { return ((idx / 7) * IR + idx % 7) * ROWB; }
 
+template <typename TIn>
 __global__ __launch_bounds__(SB_NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void stem_pool_bf16_kernel(StemBArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* patch = lds;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(SB_NT) __attribute__((amdgpu_waves_per_eu(3, 3))) v
         // together) and stores them as bf16.
         {
             float p0[NIT], p1[NIT];
-            const float* img = a.x + (size_t)n * 3 * a.H * a.W;
+            const TIn* img = reinterpret_cast<const TIn*>(a.x) + (size_t)n * 3 * a.H * a.W;
             const int ix = ix0 + lane;
             const int ixa = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
             const int ixb = ix + 64 < 0 ? 0 : (ix + 64 >= a.W ? a.W - 1 : ix + 64);
@@ -123,9 +124,9 @@ __global__ __launch_bounds__(SB_NT) __attribute__((amdgpu_waves_per_eu(3, 3))) v
                 const int c = rr / IR, r = rr - c * IR;
                 int iy = iy0 + r;
                 iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
-                const float* rowp = img + ((size_t)c * a.H + iy) * a.W;
-                p0[u] = rowp[ixa];
-                p1[u] = rowp[ixb];
+                const TIn* rowp = img + ((size_t)c * a.H + iy) * a.W;
+                p0[u] = (float)rowp[ixa];
+                p1[u] = (float)rowp[ixb];
             }
             const bool oka = (unsigned)ix < (unsigned)a.W, okb = (unsigned)(ix + 64) < (unsigned)a.W;
             unsigned char* wp = patch + (wave * ROWB + lane * 2);
@@ -237,8 +238,8 @@ namespace rpg {
 bool stem_pool_bf16_supported(int h, int w, int cout) { return cout == 64 && h >= 1 && w >= 1; }
 
 // wpack: [11][2][64] x 8 bf16 (params.pack_stem_bf16); scale / shift: the folded BatchNorm affine (fp32)
-int launch_stem_pool_bf16(const float* x_nchw, const void* wpack, const float* scale, const float* shift, void* out, int n, int h,
-                          int w, hipStream_t s) {
+int launch_stem_pool_bf16(const void* x_nchw, int x_is_bf16, const void* wpack, const float* scale, const float* shift, void* out,
+                          int n, int h, int w, hipStream_t s) {
     if (!x_nchw || !wpack || !scale || !shift || !out || n <= 0 || h <= 0 || w <= 0 || !aligned16(out) || !aligned16(wpack))
         return RPG_ERR_BAD_ARG;
     StemBArgs a{};
@@ -258,14 +259,17 @@ int launch_stem_pool_bf16(const float* x_nchw, const void* wpack, const float* s
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     static bool attr[64] = {};
     if (!attr[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_bf16_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  SB_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_bf16_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   SB_LDS_BYTES);
         attr[dev] = true;
     }
     const int slot = timing_begin(RPG_TIMER_CONV, s);
     const int grid = (int)(total < (long)SB_WGS_PER_CU * num_cus() ? total : (long)SB_WGS_PER_CU * num_cus());
     a.nxcd = (grid % 8 == 0 && n >= 64) ? 8 : 1;
-    hipLaunchKernelGGL(stem_pool_bf16_kernel, dim3(grid), dim3(SB_NT), SB_LDS_BYTES, s, a);
+    if (x_is_bf16) hipLaunchKernelGGL(stem_pool_bf16_kernel<__bf16>, dim3(grid), dim3(SB_NT), SB_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL(stem_pool_bf16_kernel<float>, dim3(grid), dim3(SB_NT), SB_LDS_BYTES, s, a);
     // algorithmic: the 7x7x3 convolution on every output pixel; executed: fragments x 11 steps x 2 MFMAs x 32*32*16*2
     timing_end(slot, 2.0 * (double)n * a.Hc * a.Wc * 64.0 * 147.0, s, (double)total * a.nfrag * KS * NF * 32768.0);
     RPG_CHECK_LAUNCH("stem_conv_bn_relu_maxpool_bf16");
@@ -276,5 +280,12 @@ int launch_stem_pool_bf16(const float* x_nchw, const void* wpack, const float* s
 
 extern "C" int rpg_stem_conv7x7s2_bn_relu_maxpool_bf16(const float* x_nchw, const void* wpack_bf16, const float* scale,
                                                        const float* shift, void* y_nhwc_bf16, int n, int h, int w, void* stream) {
-    return rpg::launch_stem_pool_bf16(x_nchw, wpack_bf16, scale, shift, y_nhwc_bf16, n, h, w, rpg::as_stream(stream));
+    return rpg::launch_stem_pool_bf16(x_nchw, 0, wpack_bf16, scale, shift, y_nhwc_bf16, n, h, w, rpg::as_stream(stream));
+}
+
+// the same kernel on an input that is ALREADY bf16 (the fp32 images rounded on the host before the H2D copy: the kernel rounds
+// them to bf16 first thing anyway, so the result is bit-identical and the PCIe transfer is half the size)
+extern "C" int rpg_stem_conv7x7s2_bn_relu_maxpool_bf16_xbf16(const void* x_nchw_bf16, const void* wpack_bf16, const float* scale,
+                                                             const float* shift, void* y_nhwc_bf16, int n, int h, int w, void* stream) {
+    return rpg::launch_stem_pool_bf16(x_nchw_bf16, 1, wpack_bf16, scale, shift, y_nhwc_bf16, n, h, w, rpg::as_stream(stream));
 }

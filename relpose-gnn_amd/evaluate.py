@@ -16,6 +16,7 @@ from typing import Iterable, List, Optional, Sequence
 import numpy as np
 import torch
 
+from . import _lib as _L
 from .graph import Batch, Data
 
 
@@ -91,22 +92,27 @@ class _InputPipeline:
     read device buffer k is done; the copy stream may overwrite it).  Graphs whose ``x`` is already pinned skip the staging
     copy; graphs already on the device skip the pipeline altogether (``evaluate_stream`` collates them on the device)."""
 
-    def __init__(self, device, rows: int, row_floats: int):
+    def __init__(self, device, rows: int, row_floats: int, dtype=torch.float32):
+        # dtype = torch.bfloat16: the images are ROUNDED TO bf16 WHILE THEY ARE STAGED (the bf16 encoder rounds its fp32 input
+        # first thing, so the forward is bit-identical) and the H2D copy is half the size -- at 256x341 the fp32 copy of a
+        # 64-graph micro-batch (537 MB, ~13.7 ms at the 39 GB/s this host reaches) outlasts the bf16 forward (9 ms)
         self.device = device
+        self.dtype = dtype
         self.copy_stream = torch.cuda.Stream(device=device)
-        self.host = [torch.empty((rows, row_floats), dtype=torch.float32, pin_memory=True) for _ in range(2)]
-        self.host_np = [t.numpy() for t in self.host]
+        self.host = [torch.empty((rows, row_floats), dtype=dtype, pin_memory=True) for _ in range(2)]
+        self.host_np = [t.numpy() for t in self.host] if dtype == torch.float32 else None
         import os
         from concurrent.futures import ThreadPoolExecutor
-        self.workers = max(1, min(8, (os.cpu_count() or 2) // 2))
+        # 8 threads reach the ~40 GB/s the host moves (memcpy for fp32 staging, rpg_host_f32_to_bf16 for bf16 staging)
+        self.workers = max(1, min(int(os.environ.get("RPG_STAGE_WORKERS", "0")) or (8 if dtype == torch.float32 else 16), (os.cpu_count() or 2) // 2))
         self.pool = ThreadPoolExecutor(max_workers=self.workers) if self.workers > 1 else None
-        self.dev = [torch.empty((rows, row_floats), dtype=torch.float32, device=device) for _ in range(2)]
+        self.dev = [torch.empty((rows, row_floats), dtype=dtype, device=device) for _ in range(2)]
         self.sent = [torch.cuda.Event() for _ in range(2)]
         self.used = [torch.cuda.Event() for _ in range(2)]
         self.n_sent = [0, 0]
 
-    def fits(self, rows: int, row_floats: int) -> bool:
-        return rows <= self.host[0].shape[0] and row_floats == self.host[0].shape[1]
+    def fits(self, rows: int, row_floats: int, dtype=torch.float32) -> bool:
+        return rows <= self.host[0].shape[0] and row_floats == self.host[0].shape[1] and dtype == self.dtype
 
     def stage(self, k: int, chunk) -> torch.Tensor:
         """Collate the chunk's node images into pinned buffer k and enqueue the H2D copy; returns the device view."""
@@ -117,7 +123,7 @@ class _InputPipeline:
         jobs = []
         for g in chunk:
             n = g.x.shape[0]
-            if g.x.is_pinned():
+            if g.x.is_pinned() and g.x.dtype == self.dtype:
                 direct.append((off, n, g.x))
             else:
                 jobs.append((off, n, g.x))
@@ -125,11 +131,20 @@ class _InputPipeline:
         if jobs:
             # pageable -> pinned by a few worker threads (numpy releases the GIL; one memcpy stream moves ~5 GB/s on the GPU
             # host, measured r3: 649 graphs/s single-threaded against 1808 with resident images at 256x341)
-            host_np = self.host_np[k]
+            host_np = self.host_np[k] if self.host_np is not None else None
+            cvt = _L.lib().rpg_host_f32_to_bf16 if host_np is None else None
 
             def copy_some(part):
                 for o, n, src in part:
-                    np.copyto(host_np[o:o + n], src.detach().numpy())
+                    if host_np is not None:
+                        np.copyto(host_np[o:o + n], src.detach().numpy())
+                    else:
+                        # fp32 -> bf16 (round to nearest even) on the way, in the library's host helper (ctypes releases the GIL)
+                        t = src.detach()
+                        if t.dtype != torch.float32 or not t.is_contiguous():
+                            host[o:o + n].copy_(t)
+                        else:
+                            _L.check(cvt(t.data_ptr(), host[o:o + n].data_ptr(), t.numel()), "host_f32_to_bf16")
             w = min(len(jobs), self.workers)
             if w <= 1:
                 copy_some(jobs)
@@ -180,7 +195,7 @@ def _collate_on_device(chunk: Sequence[Data], x_dev: torch.Tensor, device) -> Ba
 @torch.no_grad()
 def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64, pose_m=(0.0, 0.0, 0.0),
                     pose_s=(1.0, 1.0, 1.0), ref_node: int = 0, rank: int = 0, world: int = 1,
-                    stats: Optional[dict] = None) -> EvalResult:
+                    stats: Optional[dict] = None, bf16_input: Optional[bool] = None) -> EvalResult:
     """Run ``model`` over a stream of single-graph ``Data`` objects (x, edge_index, y) and post-process like test.py.
     With world > 1 every rank evaluates its contiguous block (shard_range) and the [G,7] rows are all-gathered.
 
@@ -189,7 +204,8 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
     device are collated there instead), and once both are enqueued the host post-processes micro-batch i-1, whose relative
     poses have come back through an asynchronous copy -- so neither the H2D transfer of the images (537 MB per 64 graphs
     at 256x341), nor the D2H of the poses, nor the numpy work of test.py:213-251 leaves the GPU idle.
-    ``stats`` (optional dict) receives ``h2d_bytes`` and ``staged_graphs``."""
+    ``stats`` (optional dict) receives ``h2d_bytes`` and ``staged_graphs``.  ``bf16_input`` (default: whatever the model
+    accepts, i.e. True for the bf16 encoder with its fused stem): host-resident images are rounded to bf16 while they are staged."""
     from .shard import gather_rows, shard_counts, shard_range
     pose_m, pose_s = np.asarray(pose_m, dtype=np.float64), np.asarray(pose_s, dtype=np.float64)
     lo, hi = shard_range(len(graphs), rank, world)
@@ -199,6 +215,8 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
     pipe: Optional[_InputPipeline] = None
     n_batches = 0
     h2d_bytes = 0
+    # the bf16 encoder takes its node images in bf16 (rounded while they are staged: half the H2D bytes, identical results)
+    h2d_dtype = torch.bfloat16 if (bf16_input if bf16_input is not None else getattr(model, "accepts_bf16_input", False)) else torch.float32
 
     def launch(b0):
         nonlocal pipe, n_batches, h2d_bytes
@@ -208,13 +226,13 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
         staged = on_gpu and not any(g.x.is_cuda for g in chunk)
         if staged:
             rows, width = sum(g.x.shape[0] for g in chunk), int(chunk[0].x.shape[1])
-            if pipe is None or not pipe.fits(rows, width):
+            if pipe is None or not pipe.fits(rows, width, h2d_dtype):
                 if pipe is not None:
                     torch.cuda.synchronize(device)                  # a larger buffer pair replaces one that is in flight
                 cap = max(rows, max(g.x.shape[0] for g in chunk) * micro_batch)
-                pipe = _InputPipeline(torch.device(device), cap, width)
+                pipe = _InputPipeline(torch.device(device), cap, width, h2d_dtype)
             x_dev = pipe.stage(k, chunk)
-            h2d_bytes += x_dev.numel() * 4
+            h2d_bytes += x_dev.numel() * x_dev.element_size()
             batch = _collate_on_device(chunk, x_dev, device)
             pipe.acquire(k)
         else:

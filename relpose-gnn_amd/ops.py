@@ -159,7 +159,8 @@ def stem_conv_bn_relu_maxpool(x_nchw: torch.Tensor, wpack: torch.Tensor, shift: 
 
 def stem_conv_bn_relu_maxpool_bf16(x_nchw: torch.Tensor, wpack_bf16: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
     """The bf16 encoder's stem in one kernel: fp32 [N,3,H,W] -> bf16 [N,Hp,Wp,64] (wpack_bf16 from params.pack_stem_bf16)."""
-    x_nchw, scale, shift = _req(x_nchw, "x_nchw"), _req(scale, "scale"), _req(shift, "shift")
+    xbf = x_nchw.dtype == torch.bfloat16
+    x_nchw, scale, shift = _req(x_nchw, "x_nchw", torch.bfloat16 if xbf else torch.float32), _req(scale, "scale"), _req(shift, "shift")
     wpack_bf16 = _req(wpack_bf16, "wpack_bf16", torch.bfloat16)
     n, c, h, w = x_nchw.shape
     if c != 3 or tuple(wpack_bf16.shape) != (11, 2, 64, 8) or scale.numel() != 64 or shift.numel() != 64:
@@ -167,8 +168,8 @@ def stem_conv_bn_relu_maxpool_bf16(x_nchw: torch.Tensor, wpack_bf16: torch.Tenso
     hc, wc = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     hp, wp = (hc - 1) // 2 + 1, (wc - 1) // 2 + 1
     y = torch.empty((n, hp, wp, 64), dtype=torch.bfloat16, device=x_nchw.device)
-    L.check(L.lib().rpg_stem_conv7x7s2_bn_relu_maxpool_bf16(_p(x_nchw), _p(wpack_bf16), _p(scale), _p(shift), _p(y), n, h, w,
-                                                           _stream()), "stem_conv_bn_relu_maxpool_bf16")
+    fn = L.lib().rpg_stem_conv7x7s2_bn_relu_maxpool_bf16_xbf16 if xbf else L.lib().rpg_stem_conv7x7s2_bn_relu_maxpool_bf16
+    L.check(fn(_p(x_nchw), _p(wpack_bf16), _p(scale), _p(shift), _p(y), n, h, w, _stream()), "stem_conv_bn_relu_maxpool_bf16")
     return y
 
 

@@ -139,6 +139,13 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         """'f32' (default; the 1e-4 parity path) or 'bf16' (BASELINE configs[2]: bf16 activations + bf16 MFMA convs)."""
         return self._enc.dtype
 
+    @property
+    def accepts_bf16_input(self) -> bool:
+        """True if ``data.x`` may be bf16: the bf16 encoder with the fused 64-channel stem rounds its fp32 input to bf16 first
+        thing, so images rounded on the host (``evaluate_stream``: half the H2D bytes) give bit-identical results."""
+        conv1 = getattr(self.feature_extractor, "conv1", None)
+        return self.encoder_dtype == "bf16" and conv1 is not None and tuple(conv1.weight.shape) == (64, 3, 7, 7)
+
     @encoder_dtype.setter
     def encoder_dtype(self, dtype: str) -> None:
         self._enc.set_dtype(dtype)
@@ -367,8 +374,9 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
                                "(there is no CPU fallback)")
         if not torch.is_tensor(edge_index) or edge_index.device != x.device:
             raise RuntimeError("data.edge_index must be a tensor on the same GPU as data.x")
-        if x.dtype != torch.float32:
-            raise TypeError(f"data.x must be float32 (the reference's input dtype), got {x.dtype}")
+        if x.dtype != torch.float32 and not (x.dtype == torch.bfloat16 and self.accepts_bf16_input):
+            raise TypeError(f"data.x must be float32 (the reference's input dtype; bf16 images are taken by the bf16 encoder "
+                            f"with a 64-channel stem only), got {x.dtype}")
         lib = _L.lib()
         self._poll_status(block=False)            # bad-edge report of the previous call, if it has landed
         x = x.view(x.size(0), 3, self.input_img_height, -1)                       # posenet.py:1035

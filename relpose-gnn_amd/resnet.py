@@ -105,8 +105,9 @@ class EncoderRunner:
     def run(self, state_dict_fn, prefix: str, x_nchw: torch.Tensor, slot: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if not x_nchw.is_cuda:
             raise RuntimeError("the encoder runs on the GPU only (HIP kernels, no CPU fallback); got " + str(x_nchw.device))
-        if x_nchw.dtype != torch.float32 or x_nchw.dim() != 4 or x_nchw.shape[1] != 3:
-            raise ValueError("expected fp32 [N,3,H,W]")
+        xbf = x_nchw.dtype == torch.bfloat16 and self.dtype == "bf16"     # host-rounded images for the bf16 encoder (evaluate_stream)
+        if (x_nchw.dtype != torch.float32 and not xbf) or x_nchw.dim() != 4 or x_nchw.shape[1] != 3:
+            raise ValueError("expected fp32 [N,3,H,W] (bf16 is accepted by the bf16 encoder only)")
         lib = L.lib()
         self.ensure_packed(state_dict_fn, prefix, x_nchw.device)
         tensors, blocks, planes = self._packed
@@ -120,7 +121,7 @@ class EncoderRunner:
         feat = out if out is not None else torch.empty((n, feat_dim), dtype=torch.float32, device=x.device)
         if feat.shape != (n, feat_dim) or feat.dtype != torch.float32 or not feat.is_contiguous() or feat.device != x.device:
             raise ValueError("out must be a contiguous fp32 [N, feat_dim] tensor on the input's device")
-        fwd = lib.rpg_resnet_forward_bf16 if bf16 else lib.rpg_resnet_forward_f32
+        fwd = (lib.rpg_resnet_forward_bf16_xbf16 if xbf else lib.rpg_resnet_forward_bf16) if bf16 else lib.rpg_resnet_forward_f32
         rc = fwd(self._ptrs, len(tensors), L.int_array(blocks), planes_c, feat_dim, x.data_ptr(), n, h, w, feat.data_ptr(),
                  ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
         L.check(rc, "resnet_forward")

@@ -306,6 +306,9 @@ def test_fused_stem_bf16(dev, n, h, w):
     got = y.float().cpu().permute(0, 3, 1, 2)
     assert rel_err(got, ref) < 1e-2
     assert float((got - ref).abs().mean() / ref.abs().mean().clamp(min=1e-30)) < 2e-4
+    # images already rounded to bf16 (host-side staging of evaluate_stream): the same kernel on a bf16 input, bit-identical
+    y16 = ops.stem_conv_bn_relu_maxpool_bf16(x.bfloat16().to(dev), pack_stem_bf16(wt).to(dev), scale.to(dev), shift.to(dev))
+    assert torch.equal(y16, y)
     # and the unfused three-kernel chain of the same encoder (re-layout + generic conv on 8 channels + max-pool) agrees
     w8 = F.pad(wt.permute(0, 2, 3, 1), (0, 5)).bfloat16().contiguous().to(dev)
     x8 = F.pad(x.permute(0, 2, 3, 1), (0, 5)).bfloat16().contiguous().to(dev)

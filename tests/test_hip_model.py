@@ -367,6 +367,40 @@ def test_eval_stream_input_pipeline_variants_agree(dev):
     assert np.isfinite(res["host"]).all() and res["host"].shape == (16, 7)
 
 
+def test_bf16_encoder_takes_host_rounded_bf16_images(dev):
+    """The bf16 encoder rounds its fp32 node images to bf16 first thing (fused stem), so images rounded on the HOST -- what
+    evaluate_stream does while it stages them, halving the H2D copy -- must give BIT-identical outputs: forward(x.bfloat16()) ==
+    forward(x), and evaluate_stream with bf16 staging == fp32 staging == device-resident fp32 graphs.  The fp32 encoder (and a
+    bf16 encoder without the 64-channel fused stem) refuses bf16 images."""
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd import evaluate as E
+    from relpose_gnn_amd.graph import Batch, Data, fc_edge_index
+    m, _ = _build(64, 32, (64, 16, 32, 64), (1, 1, 1, 1), dev)
+    assert not m.accepts_bf16_input
+    m.encoder_dtype = "bf16"
+    assert m.accepts_bf16_input
+    sizes = [8, 4, 8, 6, 8, 8, 5]
+    xs = [S.synth_images(n, 32, 40, seed=900 + i) for i, n in enumerate(sizes)]
+    ys = [S.hash_normal(f"bfin.y{i}", (n, 6), 0.3) for i, n in enumerate(sizes)]
+    graphs = [Data(x=x, edge_index=fc_edge_index(x.shape[0]), y=y) for x, y in zip(xs, ys)]
+    b = Batch.from_data_list(graphs[:3]).to(dev)
+    a32, r32, _ = m(b)
+    b.x = b.x.bfloat16()
+    a16, r16, _ = m(b)
+    assert torch.equal(a32, a16) and torch.equal(r32, r16)
+    res = {}
+    for kind, flag in (("bf16_staging", None), ("fp32_staging", False), ("resident", None)):
+        st = {}
+        gs = graphs if kind != "resident" else [Data(x=g.x.to(dev), edge_index=g.edge_index, y=g.y) for g in graphs]
+        res[kind] = E.evaluate_stream(m, gs, dev, micro_batch=3, stats=st, bf16_input=flag).pred_poses
+        per_elt = {"bf16_staging": 2, "fp32_staging": 4, "resident": 0}[kind]
+        assert st["h2d_bytes"] == per_elt * sum(sizes) * 3 * 32 * 40, (kind, st)
+    assert np.array_equal(res["bf16_staging"], res["fp32_staging"]) and np.array_equal(res["resident"], res["fp32_staging"])
+    m.encoder_dtype = "f32"
+    with pytest.raises(TypeError):
+        m(b)
+
+
 def test_eval_harness_with_the_reference_default_knn(dev):
     """The reference's default flags (`--knn 4`, test.py:308): the model rebuilds the graph from the encoder features
     (posenet.py:1047-1048) and eval_RP post-processes the edge list the MODEL returns.  evaluate_stream (micro-batches of 3

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--input", choices=("host", "pinned", "resident"), default="host",
                     help="where the graphs' node images live when the stream starts: pageable host memory (a plain loader), pinned "
                          "host memory (DataLoader(pin_memory=True), test.py:193), or the device (no H2D: the comparison point)")
+    ap.add_argument("--h2d", choices=("auto", "f32", "bf16"), default="auto",
+                    help="staging dtype of host-resident images: auto = bf16 where the model takes it (bf16 encoder: rounded while staged, half the H2D bytes, identical results)")
     ap.add_argument("--pool", type=int, default=96, help="distinct graphs' worth of synthetic pixels that the stream cycles through")
     args = ap.parse_args()
     h, w = (int(v) for v in args.shape.split("x"))
@@ -82,13 +84,14 @@ def main():
     graphs = [Data(x=pool[i % len(pool)][0], edge_index=ei8, y=pool[i % len(pool)][1]) for i in range(args.graphs)]
     mb = args.micro_batch
 
-    E.evaluate_stream(model, graphs[: min(2 * mb, len(graphs))], dev, micro_batch=mb)      # warm-up (packing, workspaces, staging buffers)
+    bfin = None if args.h2d == "auto" else args.h2d == "bf16"
+    E.evaluate_stream(model, graphs[: min(2 * mb, len(graphs))], dev, micro_batch=mb, bf16_input=bfin)      # warm-up (packing, workspaces, staging buffers)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     stats = {}
     t0 = time.perf_counter()
-    res = E.evaluate_stream(model, graphs, dev, micro_batch=mb, rank=rank, world=world, stats=stats)   # THE product loop
+    res = E.evaluate_stream(model, graphs, dev, micro_batch=mb, rank=rank, world=world, stats=stats, bf16_input=bfin)   # THE product loop
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -101,7 +104,8 @@ def main():
         assert len(res.pred_poses) == args.graphs and np.isfinite(res.pred_poses).all()
         print(json.dumps({"workload": f"eval-shape stream through relpose_gnn_amd.evaluate.evaluate_stream: {args.graphs} 8-node FC graphs, "
                                       f"{h}x{w}, encoder {args.encoder_dtype}, GNN Linears {args.gnn_dtype}, knn {args.knn}, micro-batch {mb}, "
-                                      f"node images {args.input} ({'pinned double-buffered H2D on a copy stream' if args.input != 'resident' else 'no H2D'}), "
+                                      f"node images {args.input} ({'pinned double-buffered H2D on a copy stream' if args.input != 'resident' else 'no H2D'}"
+                                      f"{', staged as bf16' if args.input != 'resident' and (bfin if bfin is not None else model.accepts_bf16_input) else ''}), "
                                       "D2H + test.py post-processing per graph included",
                           "input": args.input, "n_gpus": world, "graphs": args.graphs, "seconds": round(dt, 3),
                           "graphs_per_s": round(args.graphs / dt, 1),

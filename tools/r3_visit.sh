@@ -78,6 +78,14 @@ for step in "$@"; do
     ws64)
       timeout 900 python -m pytest tests/test_hip_bf16.py -q -m gpu -x -k "weights_stationary" > "$OUT/pytest_ws64.log" 2>&1; echo "pytest rc=$?"; tail -15 "$OUT/pytest_ws64.log"
       for m in 0 1 2; do echo "ws64 mode $m"; RPG_WS64=$m timeout 600 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --reps 10 --only l1.c 2>&1 | grep conv; done | tee "$OUT/ws64_512.txt";;
+    evalbf16)
+      timeout 900 python -m pytest tests/test_hip_model.py tests/test_hip_bf16.py -q -m gpu -x -k "host_rounded or fused_stem or eval_stream" > "$OUT/pytest_bfin.log" 2>&1; echo "pytest rc=$?"; tail -5 "$OUT/pytest_bfin.log"
+      for h2d in bf16 f32; do
+        timeout 600 python tools/eval_stream.py --graphs 4000 --shape 256x341 --input host --encoder-dtype bf16 --gnn-dtype bf16 --h2d $h2d >> "$OUT/eval_stream_bf16.jsonl" 2>> "$OUT/eval_stream_bf16.err"
+      done
+      timeout 600 python tools/eval_stream.py --graphs 4000 --shape 256x341 --input pinned --encoder-dtype bf16 --gnn-dtype bf16 >> "$OUT/eval_stream_bf16.jsonl" 2>> "$OUT/eval_stream_bf16.err"
+      timeout 600 python tools/eval_stream.py --graphs 4000 --shape 256x341 --input resident --encoder-dtype bf16 --gnn-dtype bf16 >> "$OUT/eval_stream_bf16.jsonl" 2>> "$OUT/eval_stream_bf16.err"
+      cut -c1-60,330-700 "$OUT/eval_stream_bf16.jsonl"; tail -3 "$OUT/eval_stream_bf16.err";;
     *) echo "unknown step $step";;
   esac
 done
