@@ -200,3 +200,23 @@ def test_stem_pair_table_matches_the_kernel():
     assert float(wp[5, 1, 7]) == 2.0 * float(w[39, a[5][0], a[5][1], a[5][2]])                      # first tap, channel 32 + 7
     assert float(wp[5, 1, 32 + 7]) == 2.0 * float(w[39, b[5][0], b[5][1], b[5][2]])                # second tap
     assert float(wp[73, 0, 40]) == 0.0                                                              # the missing partner
+
+
+def test_host_f32_to_bf16_is_round_to_nearest_even():
+    """rpg_host_f32_to_bf16 (the staging threads of evaluate_stream round the bf16 encoder's node images with it) against torch's
+    fp32 -> bf16 conversion -- which is also what the stem kernel's own (__bf16)float does -- on normal values across the whole
+    exponent range, ties, zeros, infinities, denormals, the largest finite value (rounds to inf) and every NaN payload class."""
+    from relpose_gnn_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1 << 18, generator=g) * torch.logspace(-40, 38, 1 << 18)
+    x[:10] = torch.tensor([float("nan"), float("inf"), -float("inf"), 0.0, -0.0, 1e-45, 3.3895313892515355e38, -1.0, 1.00390625, 1.01171875])
+    bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (1 << 18,), dtype=torch.int64, generator=g).to(torch.int32).view(torch.float32)
+    for t in (x, bits):
+        out = torch.empty(t.shape, dtype=torch.bfloat16)
+        assert lib.rpg_host_f32_to_bf16(t.data_ptr(), out.data_ptr(), t.numel()) == _lib.RPG_OK
+        ref = t.bfloat16()
+        nan = torch.isnan(ref)
+        assert torch.equal(out.view(torch.int16)[~nan], ref.view(torch.int16)[~nan])
+        assert torch.isnan(out[nan]).all() and nan.sum() == torch.isnan(t).sum()
+    assert lib.rpg_host_f32_to_bf16(None, None, 0) == _lib.RPG_OK and lib.rpg_host_f32_to_bf16(None, None, 4) == _lib.RPG_ERR_BAD_ARG
