@@ -263,6 +263,64 @@ def main():
              abs_both=a_k.numpy(), rel_both=r_k.numpy(), ei_both=e_k.numpy(),
              abs_fwd=a_f.numpy(), rel_fwd=r_f.numpy(), ei_fwd=e_f.numpy())
 
+    # ---- G9: on-disk artefacts written by the REFERENCE's own code -------------------------------
+    # (a) a checkpoint through niantic.utils.utils.save_checkpoint (utils.py:22-31), the G4 model (D=64, planes 8..64),
+    #     the criterion and the Adam optimiser built as training/train.py:196-214 builds them, after ONE optimiser step with
+    #     lr=0 / weight_decay=0 (weights bit-unchanged; the file then carries a real Adam state: step counters, exp_avg ...).
+    # (b) a graph sample in the layout of dataset_7Scenes_multi.py:437-446 (`torch.save(Data(x, edge_index, y, edge_attr))`):
+    #     torch_geometric is not installed, so the Data / GlobalStorage classes are stand-ins that reproduce PyG 2.0.1's
+    #     attribute layout and class paths (Data.__dict__['_store'] -> GlobalStorage.__dict__['_mapping']); the numbers are
+    #     graph 0 of the G4 input.  tests: file -> relpose_gnn_amd.io -> load_state_dict -> forward == G4.
+    tv = types.ModuleType("torchvision")
+    tv.datasets = types.ModuleType("torchvision.datasets")
+    tv.datasets.folder = types.ModuleType("torchvision.datasets.folder")
+    tv.datasets.folder.default_loader = lambda path: None
+    for name, mod in (("torchvision", tv), ("torchvision.datasets", tv.datasets), ("torchvision.datasets.folder", tv.datasets.folder)):
+        sys.modules.setdefault(name, mod)
+    from niantic.utils.utils import save_checkpoint                # the reference's writer
+    from niantic.modules.criterion import PoseNetCriterion
+    m64.load_state_dict(sd64)
+    crit = PoseNetCriterion(sax=0.0, saq=-3.0, learn_beta=True)
+    crit_R = PoseNetCriterion(sax=0.0, saq=-3.0, learn_beta=True)
+    opt = torch.optim.Adam([{"params": m64.parameters()}, {"params": [crit.sax, crit.saq]},
+                            {"params": [crit_R.sax, crit_R.saq]}], lr=0.0, weight_decay=0.0)
+    x4 = S.synth_images(16, 32, 40, seed=3)
+    m64.train()
+    a_t, r_t, _ = m64(types.SimpleNamespace(x=x4, edge_index=O.batch_edge_index(8, 2), edge_attr=None, batch=None))
+    (a_t.square().mean() + r_t.square().mean()).backward()
+    opt.step()
+    m64.eval()
+    assert all(torch.equal(v, sd64[k]) for k, v in m64.state_dict().items() if "num_batches_tracked" not in k and "running_" not in k)
+    m64.load_state_dict(sd64)                                       # (train-mode BN moved the running statistics: put them back)
+    save_checkpoint(HERE, 199, m64, opt, crit)
+    ck = torch.load(os.path.join(HERE, "epoch_199.pth.tar"), weights_only=False)
+    assert set(ck) == {"epoch", "model_state_dict", "optim_state_dict", "criterion_state_dict"} and ck["epoch"] == 199
+    assert all(torch.equal(ck["model_state_dict"][k], sd64[k]) for k in sd64) and len(ck["optim_state_dict"]["state"]) >= 60
+
+    pyg = {n: types.ModuleType(n) for n in ("torch_geometric.data", "torch_geometric.data.data", "torch_geometric.data.storage")}
+
+    class GlobalStorage:
+        def __init__(self, parent):
+            self._mapping, self._parent = {}, parent                # PyG 2.0.1 BaseStorage.__getstate__ stores the parent itself
+
+    class Data:
+        def __init__(self, **kw):
+            self._store = GlobalStorage(self)
+            self._store._mapping.update(kw)
+    GlobalStorage.__module__, GlobalStorage.__qualname__ = "torch_geometric.data.storage", "GlobalStorage"
+    Data.__module__, Data.__qualname__ = "torch_geometric.data.data", "Data"
+    pyg["torch_geometric.data.data"].Data, pyg["torch_geometric.data.storage"].GlobalStorage = Data, GlobalStorage
+    sys.modules.update(pyg)
+    ei8 = O.fc_edge_index(8)
+    y8 = S.hash_normal("g9.y", (8, 6), 0.3, 0.0, seed=9)
+    os.makedirs(os.path.join(HERE, "processed"), exist_ok=True)
+    torch.save(Data(x=x4[:8].view(8, -1).clone(), edge_index=ei8, y=y8, edge_attr=y8[ei8[0]] - y8[ei8[1]]),
+               os.path.join(HERE, "processed", "data_000000.pt"))
+    for n in pyg:
+        sys.modules.pop(n, None)
+    print("g9 checkpoint (reference save_checkpoint) + graph sample written:",
+          os.path.getsize(os.path.join(HERE, "epoch_199.pth.tar")), os.path.getsize(os.path.join(HERE, "processed", "data_000000.pt")), "bytes")
+
     # ---- G6: caller-side pose utilities ------------------------------------------------------
     rng = np.random.RandomState(7)
     v = rng.randn(6, 3) * 0.7

@@ -60,9 +60,10 @@ def test_shard_ranges():
             assert max(shard_counts(n, w)) - min(shard_counts(n, w)) <= 1
 
 
-def _eval_worker(rank, world, port, out_dir):
+def _eval_worker(rank, world, port, out_dir, n_graphs=7):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
     import numpy as np
     from relpose_gnn_amd import evaluate as E
     from relpose_gnn_amd.graph import Data, fc_edge_index
@@ -73,19 +74,22 @@ def _eval_worker(rank, world, port, out_dir):
 
     rng = np.random.RandomState(3)
     graphs = [Data(x=torch.zeros(8, 12), edge_index=fc_edge_index(8), y=torch.from_numpy(rng.randn(8, 6) * 0.2).float())
-              for _ in range(7)]
+              for _ in range(n_graphs)]
     res = E.evaluate_stream(Fake(), graphs, "cpu", micro_batch=2, rank=rank, world=world)
     np.save(os.path.join(out_dir, f"e{rank}.npy"), res.pred_poses)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_evaluation_stream(tmp_path):
-    """evaluate_stream over 2 ranks (ragged 4 + 3 graphs) == the single-process result, on every rank."""
+@pytest.mark.parametrize("world,n_graphs", [(2, 7), (4, 17), (8, 17), (8, 5)])
+def test_sharded_evaluation_stream(tmp_path, world, n_graphs):
+    """evaluate_stream over 2 / 4 / 8 ranks == the single-process result, on every rank: ragged tails (4 + 3; 17 graphs over
+    4 ranks = 5,4,4,4 and over 8 ranks = 3,2,...,2) and ranks WITHOUT a graph (5 graphs on 8 ranks: the zero-row blocks are
+    padded for the all-gather and trimmed) -- the world sizes of BASELINE.json configs[3] / [4]."""
     import numpy as np
     from relpose_gnn_amd import evaluate as E
     from relpose_gnn_amd.graph import Data, fc_edge_index
-    mp.spawn(_eval_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_eval_worker, args=(world, _free_port(), str(tmp_path), n_graphs), nprocs=world, join=True)
 
     class Fake:
         def __call__(self, b):
@@ -93,14 +97,15 @@ def test_sharded_evaluation_stream(tmp_path):
 
     rng = np.random.RandomState(3)
     graphs = [Data(x=torch.zeros(8, 12), edge_index=fc_edge_index(8), y=torch.from_numpy(rng.randn(8, 6) * 0.2).float())
-              for _ in range(7)]
+              for _ in range(n_graphs)]
     ref = E.evaluate_stream(Fake(), graphs, "cpu", micro_batch=3).pred_poses
-    for r in range(2):
+    for r in range(world):
         got = np.load(os.path.join(str(tmp_path), f"e{r}.npy"))
-        assert got.shape == (7, 7) and np.allclose(got, ref, atol=1e-6)
+        assert got.shape == (n_graphs, 7) and np.allclose(got, ref, atol=1e-6)
 
 
-def test_bench_spawns_its_own_ranks(tmp_path, capsys):
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_spawns_its_own_ranks(tmp_path, capsys, world):
     """`python bench.py --gpus N` without a torchrun environment starts N ranks as a child process and relays rank 0's
     JSON line.  The launcher is exercised here with a stand-in rank script on gloo (bench.py's own
     ranks need GPUs)."""
@@ -122,8 +127,8 @@ def test_bench_spawns_its_own_ranks(tmp_path, capsys):
         "dist.barrier(); dist.destroy_process_group()\n")
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
-    rc = bench.spawn_ranks(2, script=str(stub), argv=["--gpus", "2", "--steps", "3"])
+    rc = bench.spawn_ranks(world, script=str(stub), argv=["--gpus", str(world), "--steps", "3"])
     out = capsys.readouterr().out.strip().splitlines()
     assert rc == 0 and len(out) == 1                        # exactly ONE line on stdout: the JSON
     line = json.loads(out[0])
-    assert line["n_gpus"] == 2 and line["value"] == 3.0 and line["argv"] == ["--gpus", "2", "--steps", "3"]
+    assert line["n_gpus"] == world and line["value"] == world * (world + 1) / 2 and line["argv"] == ["--gpus", str(world), "--steps", "3"]

@@ -194,3 +194,25 @@ def test_checkpoint_reader(tmp_path):
     torch.save({"epoch": 199, "model_state_dict": sd, "optim_state_dict": {}, "criterion_state_dict": {}}, tmp_path / "epoch_199.pth.tar")
     out = rio.load_checkpoint_state_dict(str(tmp_path / "epoch_199.pth.tar"))
     assert torch.equal(out["proj_edge.weight"], sd["proj_edge.weight"])
+
+
+def test_reference_written_checkpoint_and_sample(golden_dir):
+    """VERDICT r3 item 5(b), CPU half: ``tests/golden/epoch_199.pth.tar`` was written by the REFERENCE's own
+    ``save_checkpoint`` (utils/utils.py:22-31; make_golden.py G9: the D=64 model of golden G4 + criterion + an Adam state
+    after one step) and ``processed/data_000000.pt`` carries graph 0 of the G4 input in PyG 2.0.1's ``Data`` pickle layout.
+    Both go through the PyG-free allow-list readers; the oracle forward on what they return reproduces G4 (graph 0)."""
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd import io as rio
+    sd = rio.load_checkpoint_state_dict(os.path.join(golden_dir, "epoch_199.pth.tar"))
+    want = S.synth_state_dict(S.posenet_r2_param_shapes(64, 64, 64, (8, 16, 32, 64), (1, 1, 1, 1)), seed=1)
+    assert list(sd.keys()) == list(want.keys()) and all(torch.equal(sd[k], want[k]) for k in want)
+    files = rio.processed_files(golden_dir)
+    assert [os.path.basename(f) for f in files] == ["data_000000.pt"]
+    d = rio.load_graph(files[0])
+    assert "torch_geometric" not in sys.modules
+    assert torch.equal(d.x, S.synth_images(16, 32, 40, seed=3)[:8]) and torch.equal(d.edge_index, fc_edge_index(8))
+    assert d.y.shape == (8, 6) and torch.equal(d.edge_attr, d.y[d.edge_index[0]] - d.y[d.edge_index[1]])
+    g = np.load(os.path.join(golden_dir, "g4_full_small.npz"))
+    a, r, _ = O.posenet_forward(sd, d.x, d.edge_index, 32, 2)
+    assert float((a - torch.from_numpy(g["abs"][:8])).abs().max()) < 1e-5 * float(np.abs(g["abs"]).max())
+    assert float((r - torch.from_numpy(g["rel"][:56])).abs().max()) < 1e-5 * float(np.abs(g["rel"]).max())

@@ -55,6 +55,29 @@ def test_small_model_vs_golden_g4(dev, golden_dir):
     assert ei.shape == (2, 112)
 
 
+def test_reference_written_files_to_forward_g9(dev, golden_dir):
+    """file -> ``io.load_checkpoint_state_dict`` -> ``load_state_dict`` -> forward == G4, the path of
+    testing/test.py:347-348.  The checkpoint was written by the reference's own ``save_checkpoint`` (utils/utils.py:22-31,
+    make_golden.py G9) and the graph sample has the ``Data`` pickle layout of dataset_7Scenes_multi.py:437-446."""
+    from relpose_gnn_amd import io as rio
+    from relpose_gnn_amd.graph import Batch
+    from relpose_gnn_amd.posenet import PoseNetX_R2
+    from relpose_gnn_amd.resnet import ResNet
+    m = PoseNetX_R2(ResNet((1, 1, 1, 1), (8, 16, 32, 64)), droprate=0.0, pretrained=False, feat_dim=64, edge_feat_dim=64,
+                    node_dim=64, input_img_height=32, use_gnn=True, knn=-1, use_AP=True, gnn_recursion=2)
+    checkpoint_sd = rio.load_checkpoint_state_dict(os.path.join(golden_dir, "epoch_199.pth.tar"))
+    missing = m.load_state_dict(checkpoint_sd)                   # strict: every key of the reference's file is consumed
+    assert not missing.missing_keys and not missing.unexpected_keys
+    m = m.to(dev).eval()
+    sample = rio.load_graph(rio.processed_files(golden_dir)[0])
+    a, r, ei = m(Batch.from_data_list([sample]).to(dev))
+    g = np.load(os.path.join(golden_dir, "g4_full_small.npz"))   # G4 = 2 graphs; the sample is graph 0 (graphs are independent)
+    ea = float((a.cpu() - torch.from_numpy(g["abs"][:8])).abs().max() / np.abs(g["abs"]).max())
+    er = float((r.cpu() - torch.from_numpy(g["rel"][:56])).abs().max() / np.abs(g["rel"]).max())
+    _report("g9_reference_written_checkpoint_and_sample_to_forward_vs_g4", ea, er)
+    assert ea < TOL and er < TOL and ei.shape == (2, 56), (ea, er)
+
+
 def test_resnet34_64px_vs_golden_g4b(dev, golden_dir):
     import relpose_gnn_amd.synth as S
     m, _ = _build(64, 64, (64, 128, 256, 512), (3, 4, 6, 3), dev)

@@ -133,3 +133,73 @@ def test_knn_graph_properties():
     for v in range(20):
         dv = d[e[1] == v]
         assert bool((dv[1:] >= dv[:-1]).all())                              # nearest first
+
+
+def _sklearn_knn_edges(x, k, batch):
+    """An INDEPENDENT implementation of the published algorithm behind ``torch_cluster.knn_graph(x, k, batch,
+    loop=False)`` (reference call sites posenet.py:1043-1050): scikit-learn's brute-force nearest-neighbour search, one
+    graph at a time, the query's k+1 nearest rows with the query itself removed.  Returns per target node the neighbour
+    ids (nearest first) and their Euclidean distances."""
+    from sklearn.neighbors import NearestNeighbors
+    xn, bn = x.double().numpy(), batch.numpy()
+    out = {}
+    for g in np.unique(bn):
+        idx = np.flatnonzero(bn == g)
+        nn = NearestNeighbors(n_neighbors=min(k + 1, len(idx)), algorithm="brute", metric="euclidean").fit(xn[idx])
+        dist, nbr = nn.kneighbors(xn[idx])
+        for row, v in enumerate(idx):
+            keep = [(float(d), int(idx[j])) for d, j in zip(dist[row], nbr[row]) if idx[j] != v]
+            if len(keep) > min(k, len(idx) - 1):        # the query was not among its own k+1 nearest (exact duplicates)
+                keep = keep[:min(k, len(idx) - 1)]
+            out[int(v)] = keep
+    return out
+
+
+@pytest.mark.parametrize("case", ["random", "ragged_small_graphs", "duplicate_rows", "high_dim"])
+def test_knn_graph_pinned_against_sklearn_brute_force(case):
+    """``oracle.knn_graph`` restates torch_cluster (absent here) -- pin it against an implementation
+    nobody in this repo wrote.  Neighbour SETS and nearest-first ORDER per target node must agree with scikit-learn's
+    brute-force search on random features, on graphs with fewer than k+1 nodes, and on exact duplicate rows (ties: the
+    distance sequences must agree exactly; the ids may differ only inside a group of equal distances, where the oracle
+    takes the lower index first)."""
+    pytest.importorskip("sklearn")
+    k = 4
+    if case == "random":
+        x, b = S.hash_normal("knn.sk.x", (40, 16)), torch.arange(5).repeat_interleave(8)
+    elif case == "ragged_small_graphs":                 # 8, 3 (< k+1), 1 (isolated), 5 (= k+1), 2 nodes
+        sizes = [8, 3, 1, 5, 2]
+        x = S.hash_normal("knn.sk.r", (sum(sizes), 8))
+        b = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(sizes)])
+    elif case == "duplicate_rows":
+        x = S.hash_normal("knn.sk.d", (16, 8))
+        x[3], x[5], x[12] = x[1].clone(), x[1].clone(), x[9].clone()          # exact duplicates inside both graphs
+        b = torch.arange(2).repeat_interleave(8)
+    else:
+        x, b = S.hash_normal("knn.sk.h", (24, 2048)) * 3.0, torch.arange(3).repeat_interleave(8)      # the R3 feature width
+    e = O.knn_graph(x, k, b)
+    want = _sklearn_knn_edges(x, k, b)
+    assert e.shape[1] == sum(len(v) for v in want.values())
+    xd = x.double()
+    for v in range(x.shape[0]):
+        cols = (e[1] == v).nonzero().flatten()
+        got_ids = e[0, cols].tolist()
+        got_d = [float((xd[j] - xd[v]).norm()) for j in got_ids]
+        exp_d = [d for d, _ in want[v]]
+        exp_ids = [j for _, j in want[v]]
+        assert len(got_ids) == len(exp_ids), (v, got_ids, exp_ids)
+        assert np.allclose(got_d, exp_d, rtol=1e-9, atol=1e-12), (v, got_d, exp_d)           # nearest first, same radii
+        # a tie that matters: two candidates of this graph at the same distance from v among its k+1 nearest others (the
+        # (k+1)-th included: a tie across the cut-off decides WHICH node makes the list)
+        others = sorted(float((xd[j] - xd[v]).norm()) for j in (b == b[v]).nonzero().flatten().tolist() if j != v)[:k + 1]
+        ties = any(abs(a - c) <= 1e-12 for a, c in zip(others, others[1:]))
+        if not ties:
+            assert got_ids == exp_ids, (v, got_ids, exp_ids)                                  # identical order
+        else:
+            # inside a group of equal distances only: same multiset of distances (checked above) and every id is a node of
+            # this graph at that distance; where sklearn and the oracle pick different members the oracle's is the lower id
+            assert all(int(b[j]) == int(b[v]) and j != v for j in got_ids)
+            assert sorted(got_ids) == sorted(exp_ids) or all(
+                abs(float((xd[j] - xd[v]).norm()) - d) <= 1e-12 for j, d in zip(got_ids, exp_d))
+            # torch_cluster's documented tie rule as the oracle states it: equal distances -> the lower node id first
+            cand = sorted((round(float((xd[j] - xd[v]).norm()), 12), j) for j in (b == b[v]).nonzero().flatten().tolist() if j != v)
+            assert got_ids == [j for _, j in cand[:k]], (v, got_ids, cand[:k + 1])
