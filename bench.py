@@ -47,7 +47,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--graphs", type=int, default=32, help="graphs per step per GPU (configs[1]: 32)")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=180.0,
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the secondary BASELINE.json configs (configs[2] bf16 at 64 graphs, configs[3]/[4] evaluation streams at "
+                         "256x341) that the default N=1 run measures after the headline and reports under `other_configs`")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=120.0,
                     help="budget of the whole CPU baseline leg (three thread counts x B = 1/8/32); 0 disables it")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-graph latency leg (profiling runs: keeps its launches out of the trace)")
@@ -67,6 +70,17 @@ def parse():
 
 
 CPU_THREADS_BEST = 32      # measured optimum of torch-CPU for this model on the 2 x EPYC 9575F host (tests/probes/cpu_threads_probe.py)
+
+
+def host_sockets() -> int:
+    """Sockets of the host per lscpu (0 = unknown)."""
+    try:
+        import subprocess
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        f = {ln.split(":", 1)[0].strip(): ln.split(":", 1)[1].strip() for ln in out.splitlines() if ":" in ln}
+        return int(f["Socket(s)"])
+    except Exception:
+        return 0
 
 
 def physical_cores() -> int:
@@ -148,17 +162,114 @@ def cpu_baseline(budget_s: float):
             secs += r["seconds"]
         except Exception as exc:                                     # a baseline leg must not take the bench down
             p.kill()
+            try:
+                p.communicate(timeout=10)                            # reap the child (no zombie, pipes closed)
+            except Exception:
+                pass
             sweep.append({"threads": k, "skipped": f"worker failed: {type(exc).__name__}"})
     done = [c for c in sweep if "graphs_per_s" in c]
     if not done:
         return None
     best = max(done, key=lambda c: c["graphs_per_s"])
     return {"value": best["graphs_per_s"], "unit": "graphs/s", "cores": best["threads"], "kind": "port",
-            "physical_cores": phys,
+            "physical_cores": phys, "sockets": host_sockets(),
             "sample": f"oracle forward (torch {torch.__version__} CPU fp32) of {best['graphs_per_forward']} 8-node graphs "
                       f"(= {8 * best['graphs_per_forward']} images 224x224) per call, {best['threads']} threads, 1 warm-up + median "
-                      f"of 3; fastest of the sweep threads in {counts} x graphs-per-forward in (1, 8, 32); {secs:.0f} s of CPU work",
+                      f"of 3; fastest of the sweep threads in {counts} x graphs-per-forward in (1, 8, 32) on a {host_sockets()}-socket host with "
+                      f"{phys} physical cores (no NUMA pinning: the all-cores rows lose to 8 / 32 threads because oneDNN's "
+                      f"convolutions are memory-bound across the sockets); {secs:.0f} s of CPU work",
             "sweep": sweep}
+
+
+def bf16_roofline(kt):
+    """`roofline` object of a bf16-encoder run from the library's per-launch HIP-event timings (one-stream pass): the
+    ALGORITHMIC FLOP of all encoder convolution launches / their summed durations against the dense bf16 matrix peak."""
+    c = kt["conv"]
+    tf = c["work"] / (c["ms"] * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 2), "peak": BF16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / BF16_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": "conv3x3_bf16_patch_kernel (3x3/s1 from 256 channels: input patch resident in LDS) / "
+                      "conv_bf16_dma_kernel (implicit GEMM, operands by LDS-DMA, counted vmcnt) / "
+                      "stem_pool_bf16_kernel (fused stem), all on v_mfma_f32_32x32x16_bf16",
+            "launches": c["launches"], "avg_launch_ms": round(c["ms"] / c["launches"], 4),
+            "what": "achieved = ALGORITHMIC FLOP of all the encoder's convolution launches (2 * pixels * Cout * "
+                    "kh * kw * Cin; the stem as 7x7x3) / their summed HIP-event durations in the one-stream pass"}
+
+
+def other_configs(model, args, dev):
+    """The secondary BASELINE.json configurations, measured by the SAME process right after the headline (N = 1 only) so that
+    the driver's JSON line carries them.  `value` of the line stays the fp32 configs[1] number.
+
+      configs2_bf16_encoder / configs2_bf16_all   64 graphs x 8 x 224x224 per step, bf16 encoder (+ bf16 GNN Linears), inputs
+                                                   resident, `--streams` streams; + the one-stream HIP-event pass -> `roofline`
+      configs3_eval_stream_1gpu_host_fp32          2000 graphs of 8 x 256x341 in PAGEABLE host memory through the product loop
+      configs4_eval_stream_1gpu_host_bf16          relpose_gnn_amd.evaluate.evaluate_stream (micro-batches of 64, pinned double-
+                                                   buffered H2D on a copy stream, D2H + test.py post-processing): fp32 model /
+                                                   bf16 encoder + bf16 GNN Linears with the images rounded to bf16 while staged
+    The 4- / 8-GPU sharding of configs[3] / [4] is the driver's to launch (tools/eval_stream.py under torch.distributed.run)."""
+    from relpose_gnn_amd import evaluate as E
+    from relpose_gnn_amd import ops
+    from relpose_gnn_amd.graph import Data, fc_batch, fc_edge_index
+    out = {}
+    steps = max(args.steps, 5)
+    g2 = 64
+    x2 = torch.randn((NODES * g2, 3 * IMG * IMG), generator=torch.Generator(device=dev).manual_seed(4321), device=dev)
+    d2 = fc_batch(x2, NODES)
+    try:
+        for name, gnn in (("configs2_bf16_encoder", "f32"), ("configs2_bf16_all", "bf16")):
+            model.encoder_dtype, model.gnn_dtype, model.hip_streams = "bf16", gnn, args.streams
+            for _ in range(3):
+                _, rel, _ = model(d2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                _, rel, _ = model(d2)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert bool(torch.isfinite(rel).all())
+            model.hip_streams = 1
+            model(d2)
+            ops.timing_read()
+            ops.timing_enable(True)
+            for _ in range(steps):
+                model(d2)
+            torch.cuda.synchronize()
+            ops.timing_enable(False)
+            kt = ops.timing_read()
+            out[name] = {"value": round(g2 * steps / dt, 1), "unit": "graphs/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+                         "dtype": "bf16 encoder (f32 accumulate) + f32 GNN" if gnn == "f32" else "bf16 encoder + bf16 GNN Linears (f32 accumulate)",
+                         "workload": f"BASELINE.json configs[2]: batch={g2} 8-node fully-connected graphs, 224x224, bf16 activations + MFMA "
+                                     f"conv, {args.streams} streams, inputs resident in HBM",
+                         "roofline": bf16_roofline(kt)}
+        del x2, d2
+        model.hip_streams = args.streams
+        # evaluation-shape streams: single-graph Data objects in pageable host memory, as a loader delivers them (test.py:193,211)
+        h, w, mb = 256, 341, 64
+        model.input_img_height = h
+        gen = torch.Generator().manual_seed(77)
+        ei8 = fc_edge_index(NODES)
+        pool = [(torch.randn((NODES, 3 * h * w), generator=gen), torch.randn((NODES, 6), generator=gen) * 0.3) for _ in range(64)]
+        for name, dt_name, n in (("configs3_eval_stream_1gpu_host_fp32", "f32", 2000), ("configs4_eval_stream_1gpu_host_bf16", "bf16", 4000)):
+            model.encoder_dtype = model.gnn_dtype = dt_name
+            graphs = [Data(x=pool[i % len(pool)][0], edge_index=ei8, y=pool[i % len(pool)][1]) for i in range(n)]
+            E.evaluate_stream(model, graphs[:2 * mb], dev, micro_batch=mb)              # warm-up: packing, workspaces, staging buffers
+            torch.cuda.synchronize()
+            stats = {}
+            t0 = time.perf_counter()
+            res = E.evaluate_stream(model, graphs, dev, micro_batch=mb, stats=stats)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert res.pred_poses.shape == (n, 7) and bool((res.pred_poses == res.pred_poses).all())
+            out[name] = {"value": round(n / dt, 1), "unit": "graphs/s", "seconds": round(dt, 3), "graphs": n,
+                         "dtype": "f32" if dt_name == "f32" else "bf16 encoder + bf16 GNN Linears (f32 accumulate), images staged as bf16",
+                         "h2d_gb_per_s": round(stats.get("h2d_bytes", 0) / dt / 1e9, 2),
+                         "workload": f"BASELINE.json configs[{3 if dt_name == 'f32' else 4}] shape on ONE GPU: {n} 8-node FC graphs of {h}x{w} synthetic "
+                                     f"images in pageable host memory -> evaluate_stream (micro-batch {mb}, pinned double-buffered H2D on a "
+                                     "copy stream, D2H + test.py:213-251 post-processing per graph included); the 4- / 8-GPU sharding is "
+                                     "tools/eval_stream.py under torch.distributed.run"}
+    finally:
+        model.encoder_dtype, model.gnn_dtype, model.hip_streams, model.input_img_height = "f32", "f32", args.streams, IMG
+    return out
 
 
 def spawn_ranks(n: int, script: str = None, argv=None) -> int:
@@ -330,6 +441,12 @@ def main():
         lat1 = {"latency_1graph_ms": round(1e3 * sorted(ts)[len(ts) // 2], 4),
                 "streamed_1graph_ms": round(1e3 * (time.perf_counter() - t0) / 40, 4),
                 "image_streams": int(getattr(model, "small_batch_streams", 1))}
+    others = None
+    if rank == 0 and world == 1 and args.encoder_dtype == "f32" and args.graphs == 32 and not args.no_other_configs:
+        try:
+            others = other_configs(model, args, dev)
+        except Exception as exc:                                         # a secondary leg must not take the headline down
+            others = {"error": f"{type(exc).__name__}: {exc}"}
     if under_launcher:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -356,20 +473,8 @@ def main():
                                         "none (plain single process: no launcher environment, the step ends at the rel poses)"},
         }
         if kt is not None and args.encoder_dtype == "bf16" and kt["conv"]["launches"]:
-            c = kt["conv"]
             line["config"]["workload"] = line["config"]["workload"].replace("configs[1]", "configs[2]").replace(", fp32,", ", bf16 encoder,")
-            tf = c["work"] / (c["ms"] * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": BF16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(tf / BF16_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
-                                "kernel": "conv3x3_bf16_patch_kernel (3x3/s1 from 256 channels: input patch resident in LDS) / "
-                                          "conv_bf16_dma_kernel (implicit GEMM, operands by LDS-DMA, counted vmcnt) / "
-                                          "stem_pool_bf16_kernel (fused stem), all on v_mfma_f32_32x32x16_bf16",
-                                "launches": c["launches"], "avg_launch_ms": round(c["ms"] / c["launches"], 4),
-                                "what": "achieved = ALGORITHMIC FLOP of all the encoder's convolution launches (2 * pixels * Cout * "
-                                        "kh * kw * Cin; the stem as 7x7x3) / their summed HIP-event durations in the one-stream pass",
-                                "note": "inside a tile the 256 x 256 kernels run at ~5.3 TFLOP/s per CU (54 % of 2.5 PFLOP/s / 256; "
-                                        "the clock sits near 1.9 GHz under bf16 MFMA load); the rest is tile quantisation (49 * 2^k "
-                                        "tiles on 256 CUs) and the LDS-read-bound 64- and 128-channel layers (DESIGN.md section 5)"}
+            line["roofline"] = bf16_roofline(kt)
             if kt["linear"]["launches"]:
                 v = kt["linear"]
                 line["other_kernels"] = {"linear": {"achieved": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
@@ -404,7 +509,7 @@ def main():
             # PMC counters cannot be read from inside the process: they come from a COMMITTED rocprofv3 --pmc profile of
             # this command, used only if it was taken at this batch size, and labelled with the kernel sources it saw
             from relpose_gnn_amd.build import WINOGRAD_SOURCES, source_digest
-            tpath = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_pmc_wino43.json") for r in (3, 2)) if os.path.exists(p)), None)
+            tpath = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_pmc_wino43.json") for r in (4, 3, 2)) if os.path.exists(p)), None)
             if tpath is not None:
                 with open(tpath) as f:
                     tj = json.load(f)
@@ -412,14 +517,15 @@ def main():
                     # the profile is stamped with the digest of the files named in its `digest_of` (r3: the Winograd translation
                     # unit + the shared header; r2 profiles: every kernel source)
                     same = tj.get("source_digest") == source_digest(tj.get("digest_of") or (None if "digest_of" not in tj else WINOGRAD_SOURCES))
-                    line["roofline"]["traffic"] = round(tj["traffic_bytes_per_launch"])
+                    # `traffic` only from a profile of the kernels that are running: otherwise it stays null
+                    line["roofline"]["traffic"] = round(tj["traffic_bytes_per_launch"]) if same else None
                     line["roofline"]["committed_profile"] = {
                         "file": "profiles/" + os.path.basename(tpath), "source_digest": tj.get("source_digest"),
                         "git_commit": tj.get("git_commit"), "matches_running_kernels": same,
                         "graphs_per_step": tj.get("graphs_per_step"),
                         "what": "traffic = 1024 * (2 * FETCH_SIZE + WRITE_SIZE) per launch of the main kernel, separate "
                                 "--pmc passes, read side doubled per MI355X_MICROARCH.md; NOT observed in this run",
-                        **{k: tj[k] for k in ("algorithmic_bytes_per_launch", "traffic_over_algorithmic", "mfma_busy_frac",
+                        **{k: tj[k] for k in ("traffic_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic", "mfma_busy_frac",
                                               "cu_busy_frac", "shader_clock_ghz", "executed_mfma_gflop_per_launch") if k in tj}}
             other = {}
             for k in ("conv", "linear", "attention", "scatter", "att_agg"):
@@ -456,6 +562,9 @@ def main():
         if lat1 is not None:
             line["latency_1graph"] = dict(lat1, what="one 8-node 224x224 graph per forward (the reference's batch_size=1 loop): wall time "
                                                     "per call with a host synchronisation after each / per call when 40 calls are streamed")
+        if others is not None:
+            line["other_configs"] = others
+        line["rccl_ranks_seen"] = dist.get_world_size() if under_launcher else None
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)

@@ -137,8 +137,12 @@ size_t rpg_resnet_bf16_workspace_bytes(int n, int h, int w, const int* planes);
 int rpg_resnet_forward_bf16(const void* const* tensors, int n_tensors, const int* blocks, const int* planes, int feat_dim,
                             const float* x_nchw, int n, int h, int w, float* feat, void* workspace,
                             size_t workspace_bytes, void* stream);
-/* the same forward on bf16 node images (see rpg_stem_conv7x7s2_bn_relu_maxpool_bf16_xbf16); needs the fused stem's wpack as the
- * optional last tensor (RPG_ERR_BAD_ARG without it: the three-kernel stem reads fp32 only) */
+/* the same forward on bf16 node images (see rpg_stem_conv7x7s2_bn_relu_maxpool_bf16_xbf16).  Works with either stem: the fused
+ * kernel (wpack as the optional last tensor, RPG_TUNE_FUSED_STEM on) or the three-kernel stem, whose re-layout pass reads the
+ * bf16 pixels as they are (round 4; it used to return RPG_ERR_BAD_ARG, so a tuning knob could break a caller that stages bf16).
+ * Non-finite pixels: the fused stem's padded K slots (8th kernel column, 22nd (channel, row) pair) multiply a ZERO weight with a
+ * real neighbouring pixel, so an Inf / NaN pixel just outside a 7x7 window yields NaN where the reference's conv2d stays finite;
+ * finite inputs (every image) are unaffected. */
 int rpg_resnet_forward_bf16_xbf16(const void* const* tensors, int n_tensors, const int* blocks, const int* planes, int feat_dim,
                                   const void* x_nchw_bf16, int n, int h, int w, float* feat, void* workspace,
                                   size_t workspace_bytes, void* stream);
@@ -307,10 +311,9 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
                                      pixels (default) | 2: on any eligible size | 3: as 2 with the 256 x 128 tile for every width;
                                      + 10: always three weight stages (without: four where the LDS allows -- the next step's weight fragments
                                      are then read before the barrier) */
-#define RPG_TUNE_BF16_WS64 18     /* the weights-stationary kernel of the bf16 encoder's 64 -> 64 channel 3x3 / stride-1 convolutions (ResNet
-                                     layer 1; all 73 KB of weights in a wave's registers, 4 waves per CU, input patch in LDS) -- an experiment that
-                                     measured no faster than the kernels it would replace: 0: off (default) | 1: on >= 8192 pixels,
-                                     384-pixel tiles | 2: 256-pixel tiles */
+#define RPG_TUNE_BF16_WS64 18     /* probe builds only (-DRPG_PROBE_WS64, tools/probes/conv3x3_bf16_ws64.inc: the weights-stationary layer-1
+                                     experiment of round 3, correct and not faster): 1 / 2 select it.  The product library accepts 0 and
+                                     returns RPG_ERR_BAD_ARG for anything else */
 /* HOST: fp32 -> bf16 (round to nearest even, NaN -> quiet NaN: what the device's conversion and torch's .bfloat16() do) of a
  * contiguous host array; thread-safe, called by evaluate_stream's staging threads for the bf16 encoder's node images. */
 int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);

@@ -181,10 +181,13 @@ def gnn_layer(sd: Dict[str, Tensor], p: str, x: Tensor, edge_index: Tensor, e: T
 
 def knn_graph(x: Tensor, k: int, batch: Optional[Tensor] = None) -> Tensor:
     """torch_cluster 1.5.9 ``knn_graph(x, k, batch, loop=False, flow='source_to_target')`` restated (call sites
-    posenet.py:1044-1050).  PARITY UNPINNED for this function: torch_cluster is not installed and the reference holds no
-    vectors for it; this follows the published algorithm -- for every node the k+1 nearest nodes of its own graph by
-    squared Euclidean distance (ties: lower index first), the self match removed (``row != col``); row 0 = neighbour
-    (message source), row 1 = the query node (target); grouped by target in node order, nearest first."""
+    posenet.py:1044-1050).  Pinning: torch_cluster itself is not installed and the reference holds no vectors for it, so this
+    function cannot be checked against the package; it IS checked against an independent implementation of the same
+    published algorithm -- scikit-learn's brute-force ``NearestNeighbors`` per graph (tests/test_oracle_golden.py:
+    neighbour sets and nearest-first order on random, ragged (< k+1 nodes), duplicate-row and 2048-wide cases).  The
+    algorithm: for every node the k+1 nearest nodes of its own graph by squared Euclidean distance (ties: lower index
+    first), the self match removed (``row != col``); row 0 = neighbour (message source), row 1 = the query node (target);
+    grouped by target in node order, nearest first."""
     n = x.shape[0]
     batch = torch.zeros(n, dtype=torch.int64) if batch is None else batch
     src: List[int] = []

@@ -905,267 +905,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
     bf16_tile_epilogue<FM, FN, 160 * 1024, NW>(acc, lds_raw, ep, m0, n0, a.M, a.N, wm, wn, lane, wave);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// The weights-stationary kernel (round 3): 3x3 / stride 1 / pad 1 convolutions with 64 input and 64 output channels -- ResNet
-// layer 1, a third of the bf16 encoder's time.
-//
-// Measured on the kernels above at 512 images (1.6 M output pixels): 205-250 us whichever way (im2col DMA kernel: the input is
-// fetched nine times, bound by the ~40 GB/s per CU the LDS-DMA path delivers; patch kernel: 232-245 us), ~550 TF.  With only 64
-// output channels every operand fragment read from LDS feeds ONE or TWO MFMAs (a wave tile of 64 x 64: 2 + 2 reads for 4 MFMAs):
-// the LDS read port, not the matrix pipe, is the bound.  But 64 x 64 x 9 weights are 73 KB -- they fit the REGISTERS of a wave
-// when it has a SIMD to itself (512 unified VGPRs + AccVGPRs: 288 for the weights, 96-128 for the accumulators):
-//   * 4 waves per workgroup, one workgroup per CU, persistent over tiles of 384 (or 512) consecutive output pixels; every wave
-//     loads ALL weights once per launch (72 x 16 bytes per lane; MFMA takes them from AccVGPRs directly) and owns 96 (128)
-//     pixels x 64 channels of a tile;
-//   * the input patch is the patch kernel's (virtual image rows, zero halo from out-of-range DMA lanes, one 32-channel chunk
-//     per buffer, two buffers): LDS holds nothing else, a (tile, chunk) phase needs ONE barrier (patch complete) and per 16-deep
-//     step FM ds_read_b128 for 2 FM MFMAs -- a quarter of the LDS reads per MFMA of the kernels above;
-//   * the next phase's patch (the tile's second chunk, or the next tile's first) is fetched during the current one, one 1-KB
-//     piece per wave and step; a piece is 16 slots of ONE patch row (P % 16 == 0), so its geometry is scalar work;
-//   * pixels are the MFMA's B operand: a lane ends up with 4 consecutive channels of one pixel per accumulator quad and the
-//     epilogue (scale / shift from an LDS table, bf16 residual, ReLU) stores 8 bytes per quad straight to global memory.
-// OUTCOME (r3, 512 images, profiles/r3_ws64_experiment.txt): correct (tests/test_hip_bf16.py), and NOT faster -- 196-237 us against
-// 205-245 us, so it is off by default (RPG_TUNE_BF16_WS64).  Its MFMA phases run at 37 cycles per MFMA (32 is the pipe's rate) when
-// no vector-memory instruction is in them -- but every one that is costs the lone wave of a SIMD hundreds of cycles: a 1-KB output
-// store ~540, a 1-KB patch piece ~130 (cycle counters; tools/probes/vmem_in_mfma_probe.hip reproduces it without the convolution:
-// 6 MFMAs + one store per step = 387 cycles instead of 220, + one LDS-DMA load 671, + both 1730).  A layer-1 convolution moves
-// >= 410 MB (615 MB with the residual) for 118 GFLOP: it is bound by how many memory requests the chip has in flight, and four waves
-// per CU have few.  The kernels above do the same work at the same speed with 8-16 waves per CU; what would help layer 1 is less
-// traffic (conv1 + conv2 of a block fused), not a better matrix-pipe feed.
-// MFMA of the weights-stationary kernel as inline assembly: the operand register classes are part of the design (weights of the
-// first steps and all accumulators in AccVGPRs, the other weights and the pixel fragments in VGPRs: 288 + 96..128 + 24..32
-// registers).  Through the builtin hipcc allocates every weight as a VGPR, parks the overflow in AccVGPRs (4 v_accvgpr_read per
-// MFMA) and scratch -- and a scratch reload next to a DMA issue is an s_waitcnt vmcnt(0) in the middle of the stream.
-// Hazards the compiler no longer sees: back-to-back MFMAs on one accumulator (here always FM * FN - 1 others in between) and the
-// first VALU read of an accumulator after the last MFMA (ws64_mfma_drain).
-__device__ __forceinline__ void ws64_mfma(bool w_acc, bool first, f32x16& acc, const bf16x8& w, const bf16x8& f) {
-    // (both flags are compile-time constants after unrolling)
-    if (first) {
-        if (w_acc) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "a"(w), "v"(f));
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(w), "v"(f));
-    } else {
-        if (w_acc) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(f));
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(f));
-    }
-}
-__device__ __forceinline__ void ws64_mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
-
-struct Ws64Args {
-    const __bf16* x;
-    const float* scale;                    // fp32 per output channel (folded BN) or null
-    const float* shift;
-    const __bf16* residual;                // bf16 [M][ldc] or null
-    __bf16* out;                           // bf16 [M][ldc]
-    int ldc, relu;
-    int H, W, Nimg, M, tiles;
-    int P, PR, patch_bytes, n_pieces;      // slots per patch row, patch rows, bytes per patch buffer (multiple of 1 KB), 1-KB pieces
-    unsigned magic_p16, magic_hv;          // floor(2^32 / d) + 1 for d = P / 16 and H + 2: x / d = mulhi(x, magic) for x * d < 2^32
-};
-
-template <int FM>
-__global__ __launch_bounds__(256) void conv3x3_bf16_ws64_kernel(Ws64Args a, const __bf16* __restrict__ Wt) {
-    constexpr int NW = 4, FN = 2, BM = NW * FM * 32, KS = 36;               // KS: 16-deep steps (2 chunks x 9 taps x 2)
-    constexpr int NPW = 12;                                                  // patch pieces per wave and phase, at most: steps st % 3 != 2
-    constexpr int NST = FM * 4;                                              // 1-KB output stores per wave and tile: steps st % 3 == 2 of both phases
-    static_assert(NST <= 12, "a tile's deferred stores must fit the next tile's two phases");
-    constexpr int AG = (256 - FM * FN * 16) / (FN * 4) - 1;                  // steps whose weights live in AccVGPRs (8 registers to spare)
-    constexpr int OOB = (int)0x80000000;
-    constexpr int SP = 16 + 4;                                               // slab pitch (floats): 32 pixels x 16 channels per unit
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    // LDS: two patch buffers | scale, shift (fp32) | the waves' fp32 transposition slabs | the waves' finished bf16 output tiles
-    float* aff = reinterpret_cast<float*>(lds_raw + 2 * a.patch_bytes);
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* slab = reinterpret_cast<float*>(lds_raw + 2 * a.patch_bytes + 512) + wave * (32 * SP);
-    unsigned char* obuf = lds_raw + 2 * a.patch_bytes + 512 + NW * 32 * SP * 4 + wave * (FM * 32 * 128);
-    const int H = a.H, W = a.W, HW = a.H * a.W, P = a.P, HV = a.H + 2, P16 = a.P >> 4;
-
-    // ---- the weights: step s = (chunk * 9 + tap) * 2 + g covers input channels 32 chunk + 16 g .. + 15 of kernel tap `tap`; lane l
-    // of fragment j holds output channel 32 j + (l & 31), channels + 8 (l >> 5) .. + 7: 16 contiguous bytes of W[cout][tap][cin]
-    bf16x8 breg[KS][FN];
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int chunk = s / 18, tap = (s % 18) >> 1, g = s & 1;
-            breg[s][j] = __builtin_bit_cast(
-                bf16x8, *reinterpret_cast<const uint4*>(Wt + (((j * 32 + (lane & 31)) * 9 + tap) * 64 + chunk * 32 + g * 16 + 8 * half)));
-        }
-    if (tid < 128) aff[tid] = tid < 64 ? (a.scale ? a.scale[tid] : 1.f) : (a.shift ? a.shift[tid - 64] : 0.f);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): the weights are plain registers from here on
-
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, 0x7fffffff, 0x00020000);
-    // Patch pieces.  Piece q = wave + 4 t of a buffer = its 16-byte chunks 64 q .. 64 q + 63 = the slots 16 q .. 16 q + 15 of ONE
-    // patch row (P % 16 == 0); physical chunk l & 3 of slot (l >> 2) <- logical chunk (l & 3) ^ ((slot >> 2) & 3) of that pixel.
-    // Which image row a piece shows is the same for all its lanes: lane t works it out for piece t once per tile (row_tbl), the
-    // issue itself is two v_readlane and a handful of VALU instructions (as scalar code in the MFMA stream, 40 dependent
-    // instructions per piece, the 24 pieces of a tile cost as much as its 216 MFMAs).
-    const int lc16 = 16 * ((lane & 3) ^ ((lane >> 4) & 3));
-    auto row_tbl = [&](int m0, int& t_rb, int& t_pc) {         // lane t: byte offset of piece t's image row (or OOB), its first slot's column
-        const int n_first = m0 / HW;
-        const int v0 = n_first * HV + (m0 - n_first * HW) / W; // = v(m0) - 1: the virtual row above the tile's first pixel
-        const int q = wave + NW * (lane & 15);
-        const int prow = (int)__umulhi((unsigned)q, a.magic_p16);
-        const int v = v0 + prow;
-        const int n = (int)__umulhi((unsigned)v, a.magic_hv), rr = v - n * HV - 1;
-        const bool ok = q < a.n_pieces && prow < a.PR && (unsigned)rr < (unsigned)H && n < a.Nimg;
-        t_rb = ok ? ((n * H + rr) * W - 1) * 128 : OOB;       // (- 1: slot column c shows input column c - 1)
-        t_pc = (q - prow * P16) * 16;
-        return v0;
-    };
-    auto issue_piece = [&](int t, int buf, int t_rb, int t_pc, int chunk) {
-        if (wave + NW * t < a.n_pieces) {
-            const int rb = __builtin_amdgcn_readlane(t_rb, t), pc = __builtin_amdgcn_readlane(t_pc, t);
-            const int pcol = pc + (lane >> 2);
-            const bool ok = rb != OOB && pcol >= 1 && pcol <= W;
-            const unsigned off = ok ? (unsigned)(rb + pcol * 128 + lc16) : (unsigned)OOB;
-            dma_piece16_raw(rsx, (unsigned)(buf * a.patch_bytes + (wave + NW * t) * 1024), lds_raw, off, chunk * 64);
-        }
-    };
-    // Deferred output stores.  A tile's finished bf16 rows wait in the wave's LDS output tile (16-byte chunk c of row r at chunk
-    // c ^ (r & 7)) and leave one 1-KB store (8 whole pixel rows) per step st % 3 == 2 of the NEXT tile's phases: stored from the
-    // epilogue, all CUs wrote their tiles in the same few microseconds and the kernel stood still at HBM write speed for them
-    // (measured: 62 of 180 us; with one wave per SIMD nothing else runs meanwhile).
-    uint4 ob;
-    auto store_read = [&](int k) {                             // rows 8 k .. 8 k + 7 of the wave's output tile
-        const int row = 8 * k + (lane >> 3);
-        ob = *reinterpret_cast<const uint4*>(obuf + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
-    };
-    auto store_write = [&](int k, int m0p) {
-        const int m = m0p + wave * (FM * 32) + 8 * k + (lane >> 3);
-        if (m < a.M) *reinterpret_cast<uint4*>(a.out + (size_t)m * a.ldc + 8 * (lane & 7)) = ob;
-    };
-
-    int item = blockIdx.x;
-    if (item >= a.tiles) return;
-    int rb_c, pc_c;                                            // row table of the current tile
-    int v0_c = row_tbl(item * BM, rb_c, pc_c);
-#pragma unroll
-    for (int t = 0; t < NPW; ++t) issue_piece(t, 0, rb_c, pc_c, 0);
-    int m0_prev = -1;                                          // the tile whose output is still in LDS
-
-    for (; item < a.tiles; item += gridDim.x) {
-        const bool has_next = item + (int)gridDim.x < a.tiles;
-        const int m0 = item * BM;
-        int rb_n, pc_n;
-        const int v0_n = row_tbl(has_next ? m0 + (int)gridDim.x * BM : m0, rb_n, pc_n);
-        // ---- pixel operand addresses (patch buffer 0): pixel m -> slot s0 = (v(m) - 1 - v0) * P + c; tap (kh, kw) reads slot
-        // s0 + kh * P + kw; byte address = slot * 64 + 16 * ((2 g + half) ^ ((slot >> 2) & 3)): a3 holds g = 0, g = 1 is a3 ^ 32
-        unsigned a3[FM][3];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            int m = m0 + (wave * FM + i) * 32 + (lane & 31);
-            m = m < a.M ? m : a.M - 1;
-            const int n = m / HW, rem = m - n * HW, r = rem / W, c = rem - r * W;
-            const int s0 = (n * HV + r - v0_c) * P + c;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int t = s0 + kw;
-                a3[i][kw] = (unsigned)(t * 64 + 16 * (half ^ ((t >> 2) & 3)));
-            }
-        }
-        f32x16 acc[FM][FN];                                               // written (C = 0) by the tile's first step
-        bf16x8 fr[2][FM];
-        auto read_a = [&](int set, int i, int st, unsigned boff) {        // st = 2 tap + g within the chunk
-            const int tap = st >> 1;
-            unsigned so = boff + (unsigned)((tap / 3) * P * 64);          // wave-uniform; opaque, or hipcc precomputes (and spills) all 54 sums
-            asm volatile("" : "+s"(so));
-            const unsigned ad = (a3[i][tap % 3] + so) ^ ((st & 1) ? 32u : 0u);
-            fr[set][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds_raw + ad));
-        };
-#pragma unroll
-        for (int chunk = 0; chunk < 2; ++chunk) {
-            // this phase reads buffer `chunk`; its patch was issued during the previous phase (or the prologue)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const unsigned boff = chunk ? (unsigned)a.patch_bytes : 0u;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < FM; ++i) read_a(0, i, 0, boff);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int st = 0; st < 18; ++st) {
-                const int s = chunk * 18 + st, set = st & 1;
-                const int kst = chunk * 6 + st / 3;                       // the deferred store of this step (st % 3 == 2)
-#pragma unroll
-                for (int ms = 0; ms < FM * FN; ++ms) {
-                    const int i = ms / FN, j = ms % FN;
-                    // register classes by hand (ws64_mfma): the 256 AccVGPRs hold the accumulators and the weights of the first AG
-                    // steps, the VGPRs the rest
-                    ws64_mfma(s < AG, s == 0, acc[i][j], breg[s][j], fr[set][i]);
-                    if (j == 0 && st + 1 < 18) read_a(set ^ 1, i, st + 1, boff);
-                    // one vector-memory instruction per step: a piece of the next phase's patch (chunk 1 of this tile into buffer
-                    // 1, or chunk 0 of the next tile into buffer 0), or a row block of the previous tile's output
-                    if (st % 3 != 2) {
-                        if (ms == 1) {
-                            const int t = st - st / 3;
-                            if (chunk == 0) issue_piece(t, 1, rb_c, pc_c, 1);
-                            else if (has_next) issue_piece(t, 0, rb_n, pc_n, 0);
-                        }
-                    } else if (kst < NST && m0_prev >= 0) {
-                        if (ms == 0) store_read(kst);
-                        if (ms == FM * FN - 1) store_write(kst, m0_prev);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        // ---- epilogue: accumulator element 4 q + k of fragment (i, j) = pixel (lane & 31) of the wave's i-th 32, channel
-        // 32 j + 8 q + 4 half + k.  A unit = 32 pixels x 16 channels (two quads) goes through the wave's fp32 slab; read back, a lane
-        // finishes 8 channels of one pixel (scale / shift from the LDS table, bf16 residual, ReLU) and puts the 16 bytes into the
-        // output tile.
-        {
-            const int row = lane >> 1, part = lane & 1;
-            bf16x8 rs[2];
-            auto load_res = [&](int iu, int buf) {                        // unit iu = 4 i + u
-                if (!a.residual) return;
-                const int m = m0 + (wave * FM + (iu >> 2)) * 32 + row;
-                rs[buf] = *reinterpret_cast<const bf16x8*>(a.residual + (size_t)(m < a.M ? m : a.M - 1) * a.ldc + 16 * (iu & 3) + 8 * part);
-            };
-            load_res(0, 0);
-            ws64_mfma_drain();
-#pragma unroll
-            for (int iu = 0; iu < FM * 4; ++iu) {
-                const int i = iu >> 2, u = iu & 3, j = u >> 1;
-                if (iu + 1 < FM * 4) load_res(iu + 1, (iu + 1) & 1);
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) {
-                    f32x4 y;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) y[k] = acc[i][j][4 * (2 * (u & 1) + qq) + k];
-                    *reinterpret_cast<f32x4*>(slab + (lane & 31) * SP + 8 * qq + 4 * half) = y;
-                }
-                __builtin_amdgcn_wave_barrier();
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(slab + row * SP + 8 * part);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + row * SP + 8 * part + 4);
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(aff + 16 * u + 8 * part);
-                const f32x4 c1 = *reinterpret_cast<const f32x4*>(aff + 16 * u + 8 * part + 4);
-                const f32x4 d0 = *reinterpret_cast<const f32x4*>(aff + 64 + 16 * u + 8 * part);
-                const f32x4 d1 = *reinterpret_cast<const f32x4*>(aff + 64 + 16 * u + 8 * part + 4);
-                bf16x8 o;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float y = k < 4 ? v0[k] * c0[k] + d0[k] : v1[k - 4] * c1[k - 4] + d1[k - 4];
-                    if (a.residual) y += (float)rs[iu & 1][k];
-                    o[k] = (__bf16)(a.relu ? fmaxf(y, 0.f) : y);
-                }
-                const int orow = i * 32 + row;
-                *reinterpret_cast<bf16x8*>(obuf + orow * 128 + (((2 * u + part) ^ (orow & 7)) << 4)) = o;
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        m0_prev = m0;
-        rb_c = rb_n; pc_c = pc_n; v0_c = v0_n;
-    }
-    // the last tile's output
-#pragma unroll
-    for (int k = 0; k < NST; ++k) {
-        store_read(k);
-        store_write(k, m0_prev);
-    }
-}
-
 int g_bf16_fused_stem = 1;   // RPG_TUNE_FUSED_STEM also selects the bf16 encoder's fused stem (stem_bf16.hip)
 int g_bf16_dma = 1;      // RPG_TUNE_BF16_DMA: 0 off | 1 by shape | 10 + i: configuration i of launch_dma_config wherever it is eligible
 int g_bf16_tile = -1;    // RPG_TUNE_BF16_TILE: -1 auto | 0: 64x64 | 1: 128x128 | 2: 256x64 | 3: 128x64 (interleaved kernel only)
@@ -1251,44 +990,10 @@ bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, c
     return true;
 }
 
-int g_bf16_ws64 = 0;     // RPG_TUNE_BF16_WS64: the weights-stationary kernel for 64 -> 64 channel 3x3 convolutions: 0 off (default: not faster, see the kernel) | 1: 384-pixel tiles | 2: 256
-
-// The weights-stationary kernel, if the shape is eligible (3x3, stride 1, pad 1, 64 -> 64 channels, plain bf16 epilogue)
-template <int FM>
-bool launch_ws64(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, const EpiB& ep, hipStream_t s) {
-    constexpr int BM = 4 * FM * 32;
-    constexpr long P_SLACK = 1L << 16;
-    if (c.KH != 3 || c.KW != 3 || c.stride != 1 || c.pad != 1 || c.Cin != 64 || N != 64 || c.img_elems) return false;
-    if (ep.out_f32 || ep.res_f32 || ep.out2 || !ep.out || (ep.ldc & 7) || !rpg::aligned16(ep.out) || (ep.residual && !rpg::aligned16(ep.residual)))
-        return false;
-    const int H = c.H, W = c.W, HW = H * W;
-    Ws64Args a{};
-    a.x = c.x; a.H = H; a.W = W; a.Nimg = nimg; a.M = M;
-    a.scale = ep.scale; a.shift = ep.shift; a.residual = ep.residual; a.out = reinterpret_cast<__bf16*>(ep.out); a.ldc = ep.ldc; a.relu = ep.relu;
-    a.tiles = (M + BM - 1) / BM;
-    a.P = (W + 2 + 15) / 16 * 16;
-    const int rows = (BM - 1) / W + 2, imgs = (BM - 1) / HW + 2;
-    a.PR = rows + 2 * (imgs - 1) + 2;
-    a.patch_bytes = a.PR * a.P * 64;                          // P % 16 == 0: a multiple of 1 KB
-    a.n_pieces = a.patch_bytes / 1024;
-    // LDS: two patch buffers, scale | shift, the waves' transposition slabs (32 x 20 floats), the waves' output tiles
-    const int lds = 2 * a.patch_bytes + 512 + 4 * 32 * 20 * 4 + BM * 128;
-    if (a.P < 32 || a.n_pieces > 48 || lds > 160 * 1024) return false;
-    if ((long)nimg * HW * 128 + P_SLACK >= (1L << 31) || (long)(nimg + 2) * (H + 2) >= (1L << 24)) return false;   // one buffer resource over x: 32-bit byte offsets
-    a.magic_p16 = (unsigned)((1ULL << 32) / (unsigned)(a.P / 16)) + 1u;
-    a.magic_hv = (unsigned)((1ULL << 32) / (unsigned)(H + 2)) + 1u;
-    auto kern = conv3x3_bf16_ws64_kernel<FM>;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    static bool once[64] = {};
-    if (!once[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        once[dev] = true;
-    }
-    const int grid = a.tiles < rpg::num_cus() ? a.tiles : rpg::num_cus();
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, w);
-    return true;
-}
+#ifdef RPG_PROBE_WS64
+// the weights-stationary layer-1 experiment of round 3 (correct, not faster): lives in tools/probes/, compiled in on request only
+#include "../../tools/probes/conv3x3_bf16_ws64.inc"
+#endif
 
 // configuration table of the LDS-DMA kernel (index = RPG_TUNE_BF16_DMA - 10); returns false if the index is unknown or the
 // shape is not eligible for it (Cin % BK)
@@ -1318,13 +1023,14 @@ inline int capped_grid(long items) {
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
-// fp32 [n][3][h][w] -> bf16 [n][h][w][8] (channels 3..7 zero)
-__global__ __launch_bounds__(NT) void nchw3_to_nhwc8_bf16_kernel(const float* __restrict__ x, uint4* __restrict__ y,
+// fp32 (or already-bf16) [n][3][h][w] -> bf16 [n][h][w][8] (channels 3..7 zero)
+template <typename TIn>
+__global__ __launch_bounds__(NT) void nchw3_to_nhwc8_bf16_kernel(const TIn* __restrict__ x, uint4* __restrict__ y,
                                                                  long npix, int hw) {
     for (long p = (long)blockIdx.x * NT + threadIdx.x; p < npix; p += (long)gridDim.x * NT) {
         const long n = p / hw;
         const int qd = (int)(p - n * hw);
-        const float* b = x + n * 3 * (long)hw + qd;
+        const TIn* b = x + n * 3 * (long)hw + qd;
         const bf16x8 v = {(__bf16)b[0], (__bf16)b[hw], (__bf16)b[2 * (long)hw], (__bf16)0.f,
                           (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
         y[p] = __builtin_bit_cast(uint4, v);
@@ -1397,7 +1103,11 @@ void bf16_set_tile(int t) { g_bf16_tile = t; }
 void bf16_set_dma(int v) { g_bf16_dma = v; }
 void bf16_set_patch(int v) { g_bf16_stages = v >= 10 ? 3 : 4; g_bf16_patch = v % 10; }
 void bf16_set_fused_stem(int on) { g_bf16_fused_stem = on; }
-void bf16_set_ws64(int v) { g_bf16_ws64 = v; }
+#ifdef RPG_PROBE_WS64
+int bf16_set_ws64(int v) { g_bf16_ws64 = v; return RPG_OK; }
+#else
+int bf16_set_ws64(int v) { return v == 0 ? RPG_OK : RPG_ERR_BAD_ARG; }      // the probe kernel is not in this build
+#endif
 
 // fp32 [rows][ld_src] (first `cols` columns) -> bf16 dst[rows][ld_dst] at column offset col_off (cols % 8 == 0)
 __global__ __launch_bounds__(NT) void f32_to_bf16_kernel(const float* __restrict__ src, int ld_src, __bf16* __restrict__ dst,
@@ -1502,8 +1212,10 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
     }
     // 3x3 / stride 1: the patch kernel (input pixels fetched once per 32-channel chunk instead of once per tap)
     bool done = false;
+#ifdef RPG_PROBE_WS64
     if (g_bf16_ws64 && cin == 64 && cout == 64 && M >= 8192)
         done = g_bf16_ws64 == 2 ? launch_ws64<2>(a, wp, n, (int)M, cout, ep, s) : launch_ws64<3>(a, wp, n, (int)M, cout, ep, s);
+#endif
     if (!done && g_bf16_patch && kh == 3 && kw == 3 && stride == 1 && pad == 1 && (g_bf16_patch >= 2 || M >= 8192)) {
         // measured (tools/conv_bench.py --dma-sweep, r3): from 256 output channels up the patch kernel beats the im2col DMA kernel
         // by 5-10 %; 256 x 256 tiles where they occupy at least three quarters of the CUs, else 256 x 128 (layer 4 at 256 images:
@@ -1634,12 +1346,16 @@ static int resnet_forward_bf16_impl(const void* const* tensors, int n_tensors, c
         if ((rc = rpg::launch_stem_pool_bf16(x_nchw_any, x_is_bf16, stem_pack, (const float*)tensors[1], (const float*)tensors[2], buf[0],
                                              n, h, w, s)) != RPG_OK)
             return rc;
-    } else if (x_is_bf16) {
-        return RPG_ERR_BAD_ARG;                 // the three-kernel stem reads fp32 only: convert the input (or ship the stem pack)
     } else {
+        // three-kernel stem (RPG_TUNE_FUSED_STEM = 0, non-64-channel stems, no stem pack): re-layout (from fp32, or from images
+        // the host already rounded to bf16 -- the same bits either way), generic convolution on the 8-channel image, max-pool
         const long npix = (long)n * h * w;
-        hipLaunchKernelGGL(nchw3_to_nhwc8_bf16_kernel, dim3(capped_grid(npix)), dim3(NT), 0, s, x_nchw,
-                           reinterpret_cast<uint4*>(in8), npix, h * w);
+        if (x_is_bf16)
+            hipLaunchKernelGGL(nchw3_to_nhwc8_bf16_kernel<__bf16>, dim3(capped_grid(npix)), dim3(NT), 0, s,
+                               reinterpret_cast<const __bf16*>(x_nchw_any), reinterpret_cast<uint4*>(in8), npix, h * w);
+        else
+            hipLaunchKernelGGL(nchw3_to_nhwc8_bf16_kernel<float>, dim3(capped_grid(npix)), dim3(NT), 0, s, x_nchw,
+                               reinterpret_cast<uint4*>(in8), npix, h * w);
         if ((rc = rpg::launch_conv_bf16(in8, tensors[0], (const float*)tensors[1], (const float*)tensors[2], nullptr, stem, n, h,
                                         w, 8, planes[0], 7, 7, 2, 3, 1, 0, s)) != RPG_OK)
             return rc;

@@ -314,6 +314,16 @@ int gnn_forward_impl(const float* const* tensors, int n_tensors, const void* con
         // are down to 4 conversions (encoder features, proj_edge output, 2 x the n x D/8 attention vector).  The bf16
         // tensors live in the fp32 buffers this mode does not use (raw edge update, hidden, node hidden, agg).
         typedef unsigned short bf;
+        {   // the bf16 tensors below are ALIASED onto fp32 buffers carved above: check that every one fits the buffer it is
+            // placed in (all four are exact fits today; a change to gnn_bytes() / the carving order must not silently overlap)
+            const size_t e_buf = (size_t)e * d * sizeof(float), n_buf = (size_t)n * d * sizeof(float);
+            const size_t a_buf = (size_t)(e > 2 * n ? e : 2 * n) * d * sizeof(bf);
+            if (2 * (size_t)e * d * sizeof(bf) > e_buf ||          // eb | enb in eraw, hb | mb in hid
+                (size_t)n * 2 * d * sizeof(bf) > n_buf ||          // xab [n][2d] in nhid
+                (size_t)n * d * sizeof(bf) > n_buf ||              // nhb [n][d] in agg
+                (size_t)n * c * sizeof(bf) > a_buf)                // yb [n][c] in abf
+                return RPG_ERR_WORKSPACE;
+        }
         bf* eb = reinterpret_cast<bf*>(eraw);                 // [e][d]   current edge features (A of edge_mlp.0's edge block)
         bf* enb = eb + (size_t)e * d;                         // [e][d]   raw edge update (A of mlp.0's edge block)
         bf* hb = reinterpret_cast<bf*>(hid);                  // [e][d]   hidden activations of edge_mlp / mlp

@@ -204,7 +204,7 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
     device are collated there instead), and once both are enqueued the host post-processes micro-batch i-1, whose relative
     poses have come back through an asynchronous copy -- so neither the H2D transfer of the images (537 MB per 64 graphs
     at 256x341), nor the D2H of the poses, nor the numpy work of test.py:213-251 leaves the GPU idle.
-    ``stats`` (optional dict) receives ``h2d_bytes`` and ``staged_graphs``.  ``bf16_input`` (default: whatever the model
+    ``stats`` (optional dict) receives ``h2d_bytes`` (bytes sent through the staging pipeline) and ``micro_batches``.  ``bf16_input`` (default: whatever the model
     accepts, i.e. True for the bf16 encoder with its fused stem): host-resident images are rounded to bf16 while they are staged."""
     from .shard import gather_rows, shard_counts, shard_range
     pose_m, pose_s = np.asarray(pose_m, dtype=np.float64), np.asarray(pose_s, dtype=np.float64)
@@ -236,7 +236,12 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
             batch = _collate_on_device(chunk, x_dev, device)
             pipe.acquire(k)
         else:
-            batch = Batch.from_data_list(chunk).to(device, non_blocking=True)
+            if on_gpu and not all(g.x.is_cuda for g in chunk):
+                # a chunk that mixes device- and host-resident graphs: the host ones go over one by one, the
+                # collation then happens on the device (torch.cat would refuse mixed devices)
+                batch = Batch.from_data_list([g.to(device, non_blocking=True) for g in chunk])
+            else:
+                batch = Batch.from_data_list(chunk).to(device, non_blocking=True)
         _, rel, edge_index = model(batch)
         if staged:
             pipe.release(k)

@@ -76,8 +76,16 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         if not use_gnn:
             raise NotImplementedError("use_gnn=False is outside the accelerated path (and unreachable in the reference: "
                                       "posenet.py:987-989 touches an undefined self.mlp)")
-        if not (feat_dim == node_dim == edge_feat_dim) or feat_dim % 32:
-            raise NotImplementedError("feat_dim == node_dim == edge_feat_dim, a multiple of 32, is required")
+        if not (feat_dim == node_dim == edge_feat_dim):
+            # Not a restriction of this implementation: the reference constructs such a model (posenet.py:948-953) but its
+            # forward cannot run it -- fc_xyz_R = Linear(node_dim, 3) is applied to edge_feat [E, edge_feat_dim] (:974-975,
+            # :1085-1086) and gnn1 = simpleConvEdge_upt(node_dim, ...) to x [N, feat_dim] (proj_node is commented out, :946):
+            # every unequal combination raises "mat1 and mat2 shapes cannot be multiplied" (checked by running the reference,
+            # INTEGRATION.md).  Refused at construction here, where the reference fails at the first forward.
+            raise ValueError("feat_dim, edge_feat_dim and node_dim must be equal: the reference's forward (posenet.py:1053-1086) "
+                             f"raises a shape error for any other combination (got {feat_dim}, {edge_feat_dim}, {node_dim})")
+        if feat_dim % 32:
+            raise NotImplementedError("the HIP kernels need feat_dim to be a multiple of 32")
         self.droprate = droprate
         self.input_img_height = input_img_height
         self.use_gnn, self.n_layers, self.use_attention = use_gnn, L, use_attention
@@ -141,10 +149,10 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
 
     @property
     def accepts_bf16_input(self) -> bool:
-        """True if ``data.x`` may be bf16: the bf16 encoder with the fused 64-channel stem rounds its fp32 input to bf16 first
-        thing, so images rounded on the host (``evaluate_stream``: half the H2D bytes) give bit-identical results."""
-        conv1 = getattr(self.feature_extractor, "conv1", None)
-        return self.encoder_dtype == "bf16" and conv1 is not None and tuple(conv1.weight.shape) == (64, 3, 7, 7)
+        """True if ``data.x`` may be bf16: the bf16 encoder rounds its fp32 input to bf16 first thing (the fused 64-channel stem
+        and the three-kernel stem alike, round 4: ``RPG_TUNE_FUSED_STEM=0`` no longer turns bf16 staging into an error), so
+        images rounded on the host (``evaluate_stream``: half the H2D bytes) give bit-identical results."""
+        return self.encoder_dtype == "bf16"
 
     @encoder_dtype.setter
     def encoder_dtype(self, dtype: str) -> None:
@@ -376,7 +384,7 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
             raise RuntimeError("data.edge_index must be a tensor on the same GPU as data.x")
         if x.dtype != torch.float32 and not (x.dtype == torch.bfloat16 and self.accepts_bf16_input):
             raise TypeError(f"data.x must be float32 (the reference's input dtype; bf16 images are taken by the bf16 encoder "
-                            f"with a 64-channel stem only), got {x.dtype}")
+                            f"only), got {x.dtype}")
         lib = _L.lib()
         self._poll_status(block=False)            # bad-edge report of the previous call, if it has landed
         x = x.view(x.size(0), 3, self.input_img_height, -1)                       # posenet.py:1035

@@ -71,6 +71,7 @@ class EncoderRunner:
     def __init__(self, pool: Optional[WorkspacePool] = None):
         self._packed: Optional[Tuple[List[torch.Tensor], List[int], List[int]]] = None
         self._ptrs = None
+        self._feat_dim = 0          # rows of fc.weight, read from the state dict itself (not from a position in the packed list)
         self._pool = pool if pool is not None else WorkspacePool()
         self.dtype = "f32"          # "f32": Winograd / direct f32 MFMA kernels; "bf16": bf16 activations + bf16 MFMA
 
@@ -96,6 +97,7 @@ class EncoderRunner:
             if any(v.device != device for v in sd.values() if v.is_floating_point()):
                 raise RuntimeError("encoder weights and input are on different devices")
             from . import ops
+            self._feat_dim = int(sd[prefix + "fc.weight"].shape[0])
             if self.dtype == "bf16":
                 self._packed = pack_resnet_bf16(sd, prefix)
             else:
@@ -113,7 +115,7 @@ class EncoderRunner:
         tensors, blocks, planes = self._packed
         x = x_nchw.contiguous()
         n, _, h, w = x.shape
-        feat_dim = tensors[-2].shape[0]
+        feat_dim = self._feat_dim
         planes_c = L.int_array(planes)
         bf16 = self.dtype == "bf16"
         nbytes = (lib.rpg_resnet_bf16_workspace_bytes if bf16 else lib.rpg_resnet_workspace_bytes)(n, h, w, planes_c)

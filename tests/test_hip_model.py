@@ -376,16 +376,18 @@ def test_eval_stream_input_pipeline_variants_agree(dev):
         for i, (x, y) in enumerate(zip(xs, ys)):
             if kind == "pinned" or (kind == "mixed" and i % 3 == 1):
                 x = x.clone().pin_memory()
-            elif kind == "resident":
+            elif kind == "resident" or (kind == "device_and_host" and i % 2 == 0):
                 x = x.to(dev)
             out.append(Data(x=x, edge_index=fc_edge_index(x.shape[0]), y=y))
         return out
     res = {}
-    for kind in ("host", "pinned", "mixed", "resident"):
+    for kind in ("host", "pinned", "mixed", "resident", "device_and_host"):
         st = {}
         res[kind] = E.evaluate_stream(m, stream(kind), dev, micro_batch=3, stats=st).pred_poses
-        assert st["micro_batches"] == 6 and (st["h2d_bytes"] == 0) == (kind == "resident")
-    for kind in ("pinned", "mixed", "resident"):
+        assert st["micro_batches"] == 6 and (st["h2d_bytes"] == 0) == (kind in ("resident", "device_and_host"))
+    # device_and_host: every micro-batch mixes graphs that live on the device with graphs in host memory (used to
+    # die in torch.cat); they are collated on the device, outside the staging pipeline
+    for kind in ("pinned", "mixed", "resident", "device_and_host"):
         assert np.array_equal(res[kind], res["host"]), kind
     assert np.isfinite(res["host"]).all() and res["host"].shape == (16, 7)
 
@@ -393,8 +395,8 @@ def test_eval_stream_input_pipeline_variants_agree(dev):
 def test_bf16_encoder_takes_host_rounded_bf16_images(dev):
     """The bf16 encoder rounds its fp32 node images to bf16 first thing (fused stem), so images rounded on the HOST -- what
     evaluate_stream does while it stages them, halving the H2D copy -- must give BIT-identical outputs: forward(x.bfloat16()) ==
-    forward(x), and evaluate_stream with bf16 staging == fp32 staging == device-resident fp32 graphs.  The fp32 encoder (and a
-    bf16 encoder without the 64-channel fused stem) refuses bf16 images."""
+    forward(x), and evaluate_stream with bf16 staging == fp32 staging == device-resident fp32 graphs.  The fp32 encoder refuses
+    bf16 images; the bf16 encoder takes them with either stem (fused kernel or the three-kernel fallback)."""
     import relpose_gnn_amd.synth as S
     from relpose_gnn_amd import evaluate as E
     from relpose_gnn_amd.graph import Batch, Data, fc_edge_index
@@ -419,6 +421,21 @@ def test_bf16_encoder_takes_host_rounded_bf16_images(dev):
         per_elt = {"bf16_staging": 2, "fp32_staging": 4, "resident": 0}[kind]
         assert st["h2d_bytes"] == per_elt * sum(sizes) * 3 * 32 * 40, (kind, st)
     assert np.array_equal(res["bf16_staging"], res["fp32_staging"]) and np.array_equal(res["resident"], res["fp32_staging"])
+    # RPG_TUNE_FUSED_STEM = 0: the three-kernel stem takes the host-rounded bf16 images too -- a tuning knob must
+    # not turn a working evaluation loop into an error -- and agrees with its own fp32-input run bit for bit
+    from relpose_gnn_amd import ops
+    ops.set_tuning(ops.TUNE_FUSED_STEM, 0)
+    try:
+        assert m.accepts_bf16_input
+        a16u, r16u, _ = m(b)
+        b.x = b.x.float()
+        a32u, r32u, _ = m(b)
+        unfused = E.evaluate_stream(m, graphs, dev, micro_batch=3).pred_poses
+    finally:
+        ops.set_tuning(ops.TUNE_FUSED_STEM, 1)
+    assert torch.equal(a16u, a32u) and torch.equal(r16u, r32u)
+    assert rel_err(a16u, a32) < 2e-2 and np.isfinite(unfused).all()           # fused vs three-kernel stem: one extra bf16 rounding
+    b.x = b.x.bfloat16()
     m.encoder_dtype = "f32"
     with pytest.raises(TypeError):
         m(b)
@@ -533,6 +550,20 @@ def test_gnn_fused_aggregation_equals_reference_order(dev):
     ea, er = rel_err(a1, a0), rel_err(r1, r0)
     _report("gnn_fused_aggregation_vs_reference_order_R3_64px", ea, er)
     assert ea < TOL and er < TOL, (ea, er)
+    # the bf16 GNN has TWO implementations as well: the epilogue-emitted bf16 operands aliased onto unused fp32
+    # workspace buffers (default, fuse_agg on) and the older convert-per-Linear path (fuse_agg off).  Same bf16 roundings of
+    # the same operands up to where the mean is taken, so they agree far inside the bf16 bar (2e-2 on the rel poses).
+    m.gnn_dtype = "bf16"
+    try:
+        ab1, rb1, _ = m(b)
+        ops.set_tuning(ops.TUNE_GNN_FUSE_AGG, 0)
+        ab0, rb0, _ = m(b)
+    finally:
+        ops.set_tuning(ops.TUNE_GNN_FUSE_AGG, 1)
+        m.gnn_dtype = "f32"
+    eab, erb = rel_err(ab1, ab0), rel_err(rb1, rb0)
+    _report("gnn_bf16_epilogue_emitted_vs_convert_per_linear_R3_64px", eab, erb)
+    assert erb < 1e-2 and eab < 2.5e-2 and rel_err(rb1, r1) < 3e-2, (eab, erb)
 
 
 def test_graph_replay_equals_eager(dev):

@@ -47,8 +47,10 @@ def test_tuning_and_timer_constants_match_the_header():
     assert lib.rpg_set_tuning(defs["RPG_TUNE_BK"], 24) == _lib.RPG_ERR_BAD_ARG
     assert lib.rpg_set_tuning(defs["RPG_TUNE_WINOGRAD"], 7) == _lib.RPG_ERR_BAD_ARG
     for name, key in tune.items():                                    # defaults are accepted and restore the defaults
-        default = {"TILE": -1, "BK": 0, "BF16_BK": 32, "WINO_SHORT": 0, "BF16_TILE": -1}.get(name, 1)
+        default = {"TILE": -1, "BK": 0, "BF16_BK": 32, "WINO_SHORT": 0, "BF16_TILE": -1, "BF16_WS64": 0, "SK_MIN_ITS": 8}.get(name, 1)
         assert lib.rpg_set_tuning(key, default) == 0, name
+    # the weights-stationary probe kernel is not part of the product library (tools/probes/conv3x3_bf16_ws64.inc)
+    assert lib.rpg_set_tuning(defs["RPG_TUNE_BF16_WS64"], 1) == _lib.RPG_ERR_BAD_ARG
 
 
 def test_state_dict_contract_matches_reference_inventory():
@@ -69,6 +71,10 @@ def test_state_dict_contract_matches_reference_inventory():
         m(fc_batch(torch.zeros(8, 3 * 224 * 224), 8))
     with pytest.raises(NotImplementedError):
         PoseNetX_R2(resnet34(), use_gnn=False)
+    # unequal dims: the reference's own forward raises a shape error for them (posenet.py:974-975,1085-1086)
+    for dims in ((64, 32, 64), (64, 64, 32), (32, 64, 64)):
+        with pytest.raises(ValueError):
+            PoseNetX_R2(resnet34(), feat_dim=dims[0], edge_feat_dim=dims[1], node_dim=dims[2], use_gnn=True)
     # the other constructor flags keep the reference's state-dict inventory (checked against it in make_golden.py)
     m2 = PoseNetX_R2(resnet34(), feat_dim=64, edge_feat_dim=64, node_dim=64, use_gnn=True, use_attention=True,
                      use_AP=False, L=2)
