@@ -319,6 +319,11 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
 int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
 
 #define RPG_TUNE_SK_MIN_ITS 19    /* least K steps a stream-K workgroup of the fp32 GEMM engine gets (default 8) */
+#define RPG_TUNE_INKERNEL_FIXUP 20  /* experiment of round 4, OFF by default (measured slower on MI355X): the partial tiles of a
+                                     split launch are combined by the LAST-ARRIVING workgroup of each tile inside the producing kernel (per-tile
+                                     arrival counter in the scratch block, agent-scope slab stores / loads, slabs summed in ascending k order:
+                                     same bits whoever comes last) instead of by a separate fix-up launch.  Bit 0: stream-K tiles of the fp32 GEMM
+                                     engine; bit 1: Winograd tail tiles of up to 8 parts (wino43_conv8_kernel only); + 4: up to 32 parts */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -89,7 +89,7 @@ extern "C" int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors
     for (int i = 0; i < 4; ++i) buf[i] = cv.take<float>(p.blk);
     float* pool = cv.take<float>(p.pool);
     const size_t scratch_bytes = rpg::split_scratch_bytes();
-    rpg::ScratchScope scratch(cv.take<char>(scratch_bytes), scratch_bytes);     // split-K partial tiles of this call
+    rpg::ScratchScope scratch(cv.take<char>(scratch_bytes), scratch_bytes, s);  // split-K partial tiles of this call
 
     int rc;
     int ti = 0;
@@ -238,7 +238,7 @@ int gnn_forward_impl(const float* const* tensors, int n_tensors, const void* con
     float* node3 = cv.take<float>((size_t)n * 3 * d);
     void* abf = cv.take<unsigned short>((size_t)(e > 2 * n ? e : 2 * n) * d);
     const size_t scratch_bytes = rpg::split_scratch_bytes();
-    rpg::ScratchScope scratch(cv.take<char>(scratch_bytes), scratch_bytes);
+    rpg::ScratchScope scratch(cv.take<char>(scratch_bytes), scratch_bytes, s);
 
     int rc;
     if ((rc = rpg_graph_prepare(esrc, edst, node_offset, e, n, ends, rowptr, cursor, perm, status, stream)) != RPG_OK) return rc;

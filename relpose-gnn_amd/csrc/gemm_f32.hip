@@ -111,6 +111,11 @@ constexpr int SK_MIN_NK = 32;        // tiles with fewer k-steps are not worth s
 // Library-owned scratch pool of the fine-grained entry points (see rpg_common.h): one block per (device, stream) that
 // only grows; a grown block's predecessor is retired, not freed (a captured HIP graph or work still in flight may
 // hold its address), and nothing is allocated while the stream is being captured.
+// Every scratch block starts with kCounterBytes of ARRIVAL COUNTERS (round 4): one unsigned per split tile of the launch in
+// flight, zero between launches -- the workgroup that finds itself the last contributor of a tile combines the partial slabs
+// itself (in k order) and resets the counter, so no fix-up kernel follows.  The block's owner zeroes the header once (pool:
+// at allocation; caller workspace: ScratchScope's constructor, one memset node per composite call).
+constexpr size_t kCounterBytes = 16384;          // 4096 counters: > the split tiles of any launch (< 3 x CUs)
 struct Scratch { float* p = nullptr; size_t bytes = 0; };
 std::mutex g_scratch_mu;
 std::map<std::pair<int, hipStream_t>, Scratch> g_scratch;
@@ -118,8 +123,13 @@ std::vector<float*> g_retired;
 struct ScratchTls { float* p = nullptr; size_t bytes = 0; bool on = false; };
 thread_local ScratchTls t_scratch;
 
-float* get_scratch(hipStream_t s, size_t bytes) {
-    if (t_scratch.on) return bytes <= t_scratch.bytes ? t_scratch.p : nullptr;     // caller workspace (composite forwards)
+float* get_scratch(hipStream_t s, size_t bytes, unsigned** counters = nullptr) {
+    bytes += kCounterBytes;
+    if (t_scratch.on) {                                                             // caller workspace (composite forwards)
+        if (bytes > t_scratch.bytes) return nullptr;
+        if (counters) *counters = reinterpret_cast<unsigned*>(t_scratch.p);
+        return t_scratch.p + kCounterBytes / sizeof(float);
+    }
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_scratch_mu);
@@ -131,12 +141,18 @@ float* get_scratch(hipStream_t s, size_t bytes) {
         float* np = nullptr;
         const size_t want = bytes + bytes / 4;
         if (hipMalloc(reinterpret_cast<void**>(&np), want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        // arrival counters start at zero (stream-ordered before the first kernel that uses the block; the retired block's
+        // counters are all back at zero by then: every launch resets what it counted)
+        if (hipMemsetAsync(np, 0, kCounterBytes, s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(np); return nullptr; }
         if (sc.p) g_retired.push_back(sc.p);
         sc.p = np;
         sc.bytes = want;
     }
-    return sc.p;
+    if (counters) *counters = reinterpret_cast<unsigned*>(sc.p);
+    return sc.p + kCounterBytes / sizeof(float);
 }
+int g_inkernel_fixup = 0;            // RPG_TUNE_INKERNEL_FIXUP (bit 0: stream-K, bit 1: Winograd): partial tiles combined by the last-arriving
+                                     // workgroup instead of a fix-up launch.  OFF by default: measured slower
 
 constexpr int MAX_DEV = 64;
 int cu_count() {
@@ -256,14 +272,18 @@ namespace rpg {
 
 bool gnn_split_enabled() { return g_gnn_split != 0; }
 bool gnn_fuse_agg_enabled() { return g_gnn_fuse_agg != 0; }
-float* stream_scratch(hipStream_t s, size_t bytes) { return get_scratch(s, bytes); }
-ScratchScope::ScratchScope(void* p, size_t bytes) {
+float* stream_scratch(hipStream_t s, size_t bytes, unsigned** counters) { return get_scratch(s, bytes, counters); }
+bool inkernel_fixup_enabled() { return (g_inkernel_fixup & 2) != 0; }      // (the Winograd launcher asks)
+ScratchScope::ScratchScope(void* p, size_t bytes, hipStream_t s) {
+    // the arrival counters at the head of the slice must be zero when the first split launch of this call starts: the
+    // slice is a piece of a workspace that other calls use for other things in between
+    if (p && bytes >= kCounterBytes && hipMemsetAsync(p, 0, kCounterBytes, s) != hipSuccess) { (void)hipGetLastError(); p = nullptr; bytes = 0; }
     t_scratch.p = static_cast<float*>(p);
-    t_scratch.bytes = bytes;
+    t_scratch.bytes = p ? bytes : 0;
     t_scratch.on = true;
 }
 ScratchScope::~ScratchScope() { t_scratch = ScratchTls{}; }
-size_t split_scratch_bytes() { return (size_t)2 * 3 * cu_count() * 65536; }
+size_t split_scratch_bytes() { return (size_t)2 * 3 * cu_count() * 65536 + kCounterBytes; }
 int num_cus() { return cu_count(); }
 
 int launch_conv(const float* x, const float* w, const float* scale, const float* shift, const float* residual,
@@ -377,6 +397,11 @@ extern "C" int rpg_set_tuning(int key, int value) {
         case RPG_TUNE_EPILOGUE: g_epi_lds = value != 0; return RPG_OK;
         case RPG_TUNE_STREAMK: g_streamk = value != 0; return RPG_OK;
         case RPG_TUNE_BF16_BK: if (value != 32 && value != 64) return RPG_ERR_BAD_ARG; rpg::bf16_set_bk(value); return RPG_OK;
+        case RPG_TUNE_INKERNEL_FIXUP:      // bit 0: stream-K tiles of the GEMM engine, bit 1: Winograd tail tiles (<= 8 parts); + 4: <= 32 parts
+            if (value < 0 || value > 7) return RPG_ERR_BAD_ARG;
+            g_inkernel_fixup = value & 3;
+            rpg::wino_combine_max_set((value & 4) ? 32 : 8);
+            return RPG_OK;
         case RPG_TUNE_GNN_SPLIT: g_gnn_split = value != 0; return RPG_OK;
         case RPG_TUNE_GNN_FUSE_AGG: g_gnn_fuse_agg = value != 0; return RPG_OK;
         case RPG_TUNE_FAST_LOADER: g_fast = value != 0; return RPG_OK;

@@ -288,6 +288,7 @@ __device__ __forceinline__ void wino43_epilogue_partial(const f32x16 (&acc)[P], 
                                                         float* __restrict__ dst, Mid mid = Mid()) {
     constexpr int EP = 32 + 4;
     const int c4 = lane & 7, pr = lane >> 3;
+    const __amdgpu_buffer_rsrc_t rd = rpg::agent_rsrc(dst);           // dst is workgroup-uniform
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -312,7 +313,8 @@ __device__ __forceinline__ void wino43_epilogue_partial(const f32x16 (&acc)[P], 
             const int prow = pr + 8 * it;                               // (tile, pixel-in-half)
             const float4 v = *reinterpret_cast<const float4*>(&slab[prow * EP + 4 * c4]);
             const int px = 4 * (mw + (prow >> 1)) + 2 * half + (prow & 1);
-            *reinterpret_cast<float4*>(dst + px * BN + nw + 4 * c4) = v;
+            // agent-scope store (written through the XCD's L2): another workgroup of this launch may add the slabs up
+            rpg::agent_store_f4(rd, 4u * (unsigned)(px * BN + nw + 4 * c4), 0, v);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -540,7 +542,10 @@ RPG_F4_OP(sub4, pk_sub)
 // The n_split = (tiles - tile_base) * parts split workgroups are the FIRST blocks of the same launch as the whole tiles
 // (round 2): as a launch of their own (round 1) they ran after the main kernel on a third of the CUs for ~25 us per
 // convolution; now they are over before the first round of whole tiles ends and only the fix-up kernel follows.
-struct Split { int tile_base, parts, n_split; float* partial; };
+// arrive (round 4): per tail tile arrival counters, zero between launches.  Non-null: the workgroup that stores the LAST of a
+// tile's `parts` slabs adds them in k order and applies the epilogue itself (wino43_combine_last); null: wino43_fixup_kernel
+// does it in a launch of its own.
+struct Split { int tile_base, parts, n_split; float* partial; unsigned* arrive; };
 
 #ifdef RPG_WINO_TRACE
 // Timeline instrumentation (tools/probes/wino_trace.sh): per workgroup {HW_ID, s_memtime at entry, after the prologue, after
@@ -553,6 +558,59 @@ __device__ unsigned long long* g_wino_trace = nullptr;
 #else
 #define RPG_TRACE(i) do {} while (0)
 #endif
+
+// BatchNorm / residual / ReLU / store of one 16-byte group of a summed tail tile: pixel p (0..511) x channel quad c4 (0..15)
+__device__ __forceinline__ void wino43_finish_quad(const float4& s, const Epi& ep, int tile, int p, int c4, int M, int Tw, int W,
+                                                   int Cout, int tiles_n) {
+    const int m = (tile / tiles_n) * BMT8 + (p >> 2), nb = (tile % tiles_n) * BN + 4 * c4;
+    if (m >= M || nb >= Cout) return;
+    const int t = m / Tw, wo = 4 * (m - t * Tw) + (p & 3);
+    if (wo >= W) return;
+    const size_t o = ((size_t)t * W + wo) * Cout + nb;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero(), rs = f4zero();
+    if (ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + nb);
+    if (ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + nb);
+    if (ep.residual) rs = *reinterpret_cast<const float4*>(ep.residual + o);
+    float4 y;
+    y.x = s.x * sc.x + sh.x + rs.x; y.y = s.y * sc.y + sh.y + rs.y;
+    y.z = s.z * sc.z + sh.z + rs.z; y.w = s.w * sc.w + sh.w + rs.w;
+    if (ep.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+    *reinterpret_cast<float4*>(ep.out + o) = y;
+}
+
+// In-kernel combine of the split-K parts (round 4), called by every thread of an 8-wave workgroup right after it has stored
+// partial slab `part` of tail tile tt (agent-scope stores, see rpg_common.h).  Thread 0 takes a ticket from the tile's arrival
+// counter, and the workgroup that holds the last ticket adds all `parts` slabs in ascending k order (its own included, read
+// back like the others: the bits do not depend on who came last), applies the epilogue and puts the counter back to zero --
+// the work of wino43_fixup_kernel without the launch.  Nobody waits (no spinning: the workgroups of two streams share the
+// CUs).  `flag`: one int of LDS that no wave is using.  8 of a thread's 16 groups at a time: 8 loads in flight per thread.
+__device__ __forceinline__ void wino43_combine_last(const Split& sp, int tt, const Epi& ep, int M, int Tw, int W, int Cout,
+                                                    int tiles_n, int* flag) {
+    if (!rpg::last_arriver(sp.arrive + tt, (unsigned)sp.parts, flag)) return;
+    const __amdgpu_buffer_rsrc_t rs = rpg::agent_rsrc(sp.partial + (size_t)tt * sp.parts * (BMT8 * 4 * BN));
+    constexpr unsigned SLAB_B = BMT8 * 4 * BN * 4;
+    const int tile = sp.tile_base + tt;
+    const int tid_c = threadIdx.x;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        const unsigned vo = 16u * (unsigned)(tid_c + h * 8 * NT8);          // group idx = tid + NT8 * (8 h + c): px = idx >> 4, c4 = idx & 15
+        float4 sum[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sum[c] = rpg::agent_load_f4(rs, vo + 16u * c * NT8, 0);
+        for (int i = 1; i < sp.parts; ++i) {
+            float4 v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = rpg::agent_load_f4(rs, vo + 16u * c * NT8, (unsigned)i * SLAB_B);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { sum[c].x += v[c].x; sum[c].y += v[c].y; sum[c].z += v[c].z; sum[c].w += v[c].w; }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int idx = tid_c + NT8 * (8 * h + c);
+            wino43_finish_quad(sum[c], ep, tile, idx >> 4, idx & 15, M, Tw, W, Cout, tiles_n);
+        }
+    }
+}
 
 __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restrict__ x, const float* __restrict__ U, int H,
                                                           int W, int Cin, int Cout, int Tw, int M, Epi ep, int tiles_n,
@@ -762,10 +820,11 @@ __global__ __launch_bounds__(NT8) void wino43_conv8_kernel(const float* __restri
     __syncthreads();                     // LDS becomes the epilogue slabs
     RPG_TRACE(3);
     const int ws = __builtin_amdgcn_readfirstlane(wave);       // wave-uniform by construction: scalar addressing below
-    if (is_split)
+    if (is_split) {
         wino43_epilogue_partial(acc, lds + ws * (64 * 36), lane, (ws >> 1) * 32, (ws & 1) * 32,
                                 sp.partial + (size_t)blockIdx.x * (BMT8 * 4 * BN));
-    else
+        if (sp.arrive) wino43_combine_last(sp, tile - sp.tile_base, ep, M, Tw, W, Cout, tiles_n, reinterpret_cast<int*>(lds));
+    } else
         wino43_epilogue(acc, lds + ws * (64 * 36), lane, m0 + (ws >> 1) * 32, n0 + (ws & 1) * 32, M, Tw, W, Cout, ep);
 #ifdef RPG_WINO_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1037,6 +1096,10 @@ __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restr
         // the item loop and spills it around the K loop (82 VGPRs, reloaded from scratch on the critical path)
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
+        // (No in-kernel combine of the split parts here, unlike wino43_conv8_kernel: this kernel sits at 256 VGPRs with no
+        // scratch, and with wino43_combine_last inlined after the partial epilogue hipcc spilled five LDS-address registers
+        // whose reloads -- each an s_waitcnt vmcnt(0) -- landed inside the K loop (round 4, -Rpass-analysis=kernel-resource-usage:
+        // 20-44 bytes of scratch per lane).  Its launches are the many-tile ones, where the 6-us fix-up launch is 2 % of the kernel.)
         if (c_item < sp.n_split)
             wino43_epilogue_partial(acc, slab, lane_e, (ws >> 1) * 32, (ws & 1) * 32,
                                     sp.partial + (size_t)c_item * (BMT8 * 4 * BN), refetch);
@@ -1053,32 +1116,18 @@ __global__ __launch_bounds__(NT8) void wino43_conv8p_kernel(const float* __restr
     }
 }
 
-// Sums the `parts` partial slabs of tail tile blockIdx.x / 32 in k order and applies BatchNorm / residual / ReLU.
+// Sums the `parts` partial slabs of tail tile blockIdx.x / 32 in k order and applies BatchNorm / residual / ReLU (the separate
+// fix-up launch: RPG_TUNE_INKERNEL_FIXUP = 0, and launches whose part count is above what one workgroup should add up).
 __global__ __launch_bounds__(256) void wino43_fixup_kernel(const float* __restrict__ partial, Epi ep, int M, int Tw, int W,
                                                            int Cout, int tiles_n, Split sp) {
     const int tt = blockIdx.x >> 5, idx = (blockIdx.x & 31) * 256 + threadIdx.x;      // 512 px x 16 channel quads
-    const int p = idx >> 4, c4 = idx & 15;
-    const float* src = partial + (size_t)tt * sp.parts * (BMT8 * 4 * BN) + p * BN + 4 * c4;
+    const float* src = partial + (size_t)tt * sp.parts * (BMT8 * 4 * BN) + 4 * idx;
     float4 s = *reinterpret_cast<const float4*>(src);
     for (int i = 1; i < sp.parts; ++i) {
         const float4 v = *reinterpret_cast<const float4*>(src + (size_t)i * (BMT8 * 4 * BN));
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    const int tile = sp.tile_base + tt;
-    const int m = (tile / tiles_n) * BMT8 + (p >> 2), nb = (tile % tiles_n) * BN + 4 * c4;
-    if (m >= M || nb >= Cout) return;
-    const int t = m / Tw, wo = 4 * (m - t * Tw) + (p & 3);
-    if (wo >= W) return;
-    const size_t o = ((size_t)t * W + wo) * Cout + nb;
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero(), rs = f4zero();
-    if (ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + nb);
-    if (ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + nb);
-    if (ep.residual) rs = *reinterpret_cast<const float4*>(ep.residual + o);
-    float4 y;
-    y.x = s.x * sc.x + sh.x + rs.x; y.y = s.y * sc.y + sh.y + rs.y;
-    y.z = s.z * sc.z + sh.z + rs.z; y.w = s.w * sc.w + sh.w + rs.w;
-    if (ep.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
-    *reinterpret_cast<float4*>(ep.out + o) = y;
+    wino43_finish_quad(s, ep, sp.tile_base + tt, idx >> 4, idx & 15, M, Tw, W, Cout, tiles_n);
 }
 
 // U[xi][co][kh][c] = sum_j G[xi][j] * w[co][kh][j][c], evaluated in double and rounded once.
@@ -1105,6 +1154,8 @@ int g_wino_split_steps = 3;              // ... and the least number of K steps 
                                          // their part count is bound by CUs / tail tiles)
 int g_wino = 1;                          // RPG_TUNE_WINOGRAD: 0 off | 1 auto | 2 / 3: always the 4-wave / 8-wave kernel
 int g_wino_persist = 1;                  // RPG_TUNE_WINO_PERSIST: the persistent 8-wave kernel when a launch has more tiles than CUs
+int g_wino_combine_max = 8;              // most parts of a tail tile that its last-arriving workgroup adds up itself (one CU reads parts x 128 KB:
+                                         // beyond this the 32-blocks-per-tile fix-up launch is the faster way); RPG_TUNE_INKERNEL_FIXUP >= 2 sets it
 
 }  // namespace
 
@@ -1115,6 +1166,7 @@ void wino_set(int on) { g_wino = on; }
 void wino_split_set(int v) { g_wino_split = v != 0; g_wino_split_steps = v >= 2 ? v : 3; }
 void wino_short_set(int) {}              // RPG_TUNE_WINO_SHORT: retired with the short-K kernel (accepted, ignored)
 void wino_persist_set(int on) { g_wino_persist = on; }      // 2: also for launches of at most one tile per CU
+void wino_combine_max_set(int v) { g_wino_combine_max = v; }
 
 // Winograd needs (a) 32-bit buffer offsets (checked again by the launcher) and (b) enough work to occupy the chip.  Since
 // the 8-wave kernel cuts a grid that does not fill the CUs along K (split-K tail), that is little: from 16 units of 64
@@ -1172,7 +1224,7 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
         const int S = num_cus(), kpr = (cin + BK - 1) / BK, nk = 3 * kpr;
         executed = (double)T * nk * 48.0 * 8.0 * 4096.0;
         long t_main = T;
-        Split sp{0, 1, 0, nullptr};
+        Split sp{0, 1, 0, nullptr, nullptr};
         const long tail = T % S;
         if (g_wino_persist && cin % BK == 0 && (T > S || g_wino_persist == 2) && h >= 2) {
             // more tiles than CUs: the persistent kernel, S workgroups walking items b, b + S, ...; the tail tiles are cut
@@ -1206,14 +1258,16 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
             if (parts > kpr) parts = kpr;               // a part is at least one channel block (3 K steps)
             if (parts > nk / g_wino_split_steps && nk / g_wino_split_steps >= 2) parts = nk / g_wino_split_steps;
             if (parts >= 2) {
-                sp.partial = stream_scratch(s, (size_t)tail * parts * (BMT8 * 4 * BN) * sizeof(float));
+                unsigned* counters = nullptr;
+                sp.partial = stream_scratch(s, (size_t)tail * parts * (BMT8 * 4 * BN) * sizeof(float), &counters);
                 if (sp.partial) { sp.parts = parts; t_main = T - tail; sp.tile_base = (int)t_main; sp.n_split = (int)(tail * parts); }
+                if (sp.partial && inkernel_fixup_enabled() && parts <= g_wino_combine_max) sp.arrive = counters;
             }
         }
         // one launch: the split workgroups first, then the whole tiles
         hipLaunchKernelGGL(wino43_conv8_kernel, dim3((unsigned)(sp.n_split + t_main)), dim3(NT8), LDS8_BYTES, s, x, u, h, w, cin,
                            cout, tw, (int)M, ep, tn, sp);
-        if (sp.n_split)
+        if (sp.n_split && !sp.arrive)
             hipLaunchKernelGGL(wino43_fixup_kernel, dim3((unsigned)(T - t_main) * 32), dim3(256), 0, s, sp.partial, ep, (int)M, tw, w,
                                cout, tn, sp);
     } else {

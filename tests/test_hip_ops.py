@@ -550,3 +550,86 @@ def test_composite_abi_error_codes(dev):
     assert rc == _lib.RPG_ERR_BAD_ARG
     with pytest.raises(_lib.RpgError):
         _lib.check(_lib.RPG_ERR_WORKSPACE, "x")
+
+
+# ---- in-kernel combine of split-K / stream-K partial tiles (round 4) ------------------------------------------------------
+def _with_fixup_mode(mode, fn):
+    from relpose_gnn_amd import ops
+    ops.set_tuning(ops.TUNE_INKERNEL_FIXUP, mode)
+    try:
+        return fn()
+    finally:
+        ops.set_tuning(ops.TUNE_INKERNEL_FIXUP, 0)
+
+
+@pytest.mark.parametrize("n,h,c,res", [
+    (8, 56, 64, True),        # one 8-node graph, layer 1: 49 tiles, all split 4 ways (the reference's batch_size=1 loop, test.py:192)
+    (8, 28, 128, True),       # layer 2 of one graph: 26 tiles x 8 parts
+    (8, 14, 256, False),      # layer 3: 16 tiles x 16 parts -- above the in-kernel limit: separate fix-up launch unless mode = 32
+    (128, 7, 512, True),      # layer 4 of a 16-graph half batch: 112 tiles x 2 parts (the configs[1] two-stream geometry)
+    (5, 37, 68, True),        # ragged: 37 -> 40 wide rows, Cout % 64 != 0, partial last tile
+])
+def test_winograd_split_parts_combined_by_last_arriver(dev, n, h, c, res):
+    """The tail tiles of wino43_conv8_kernel are cut along K; the workgroup that stores a tile's LAST part adds the parts in
+    k order and applies BatchNorm / residual / ReLU itself (per-tile arrival counter, RPG_TUNE_INKERNEL_FIXUP bit 1) instead of
+    a wino43_fixup_kernel launch (0, the default: the in-kernel form measured slower).  Asserted: same result as the fix-up launch (same sums in the same order; 1e-6 allows
+    a different FMA contraction), both <= 2e-5 of F.conv2d, and BITWISE run-to-run determinism over 6 runs -- whichever
+    workgroup arrives last, the bits are the same.  Mode 6 (= 2 + 4) pushes the 16-part shape through the in-kernel path too."""
+    from relpose_gnn_amd import ops
+    g = torch.Generator().manual_seed(500 + h + c)
+    x = torch.randn(n, c, h, h + (3 if c == 68 else 0), generator=g)
+    wt = torch.randn(c, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5
+    scale, shift = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    r = torch.randn(x.shape, generator=g) if res else None
+    ref = F.conv2d(x, wt, None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref = F.relu(ref + r) if res else F.relu(ref)
+    nh = lambda t: None if t is None else t.permute(0, 2, 3, 1).contiguous().to(dev)
+    u = ops.wino43_transform_weights(nh(wt))
+    xd, rd, sc, sh = nh(x), nh(r), scale.to(dev), shift.to(dev)
+    ops.set_tuning(ops.TUNE_WINOGRAD, 3)
+    try:
+        run = lambda: ops.conv3x3_wino43_bn_act_nhwc(xd, u, sc, sh, rd, relu=True)
+        y_launch = _with_fixup_mode(0, run)
+        outs = {mode: [_with_fixup_mode(mode, run) for _ in range(6 if mode == 2 else 3)] for mode in (2, 6)}
+    finally:
+        ops.set_tuning(ops.TUNE_WINOGRAD, 1)
+    assert rel_err(y_launch.cpu().permute(0, 3, 1, 2), ref) < 2e-5
+    for mode, ys in outs.items():
+        assert all(torch.equal(y, ys[0]) for y in ys[1:]), f"mode {mode}: not deterministic"
+        assert rel_err(ys[0], y_launch) < 1e-6, mode
+        assert rel_err(ys[0].cpu().permute(0, 3, 1, 2), ref) < 2e-5, mode
+
+
+@pytest.mark.parametrize("m,k,n_out,gather,res", [
+    (1792, 2048, 2048, False, True),      # a GNN edge Linear at configs[1]: 224 tiles of 128 x 128 on 512 slots, every tile stream-K split
+    (256, 4096, 2048, False, False),      # mlp_updating.0 on the node rows: 32 tiles, K cut 8+ ways
+    (448, 6144, 2048, True, True),        # edge_mlp.0 in the reference formulation (3 gathered sources) for one 8-graph group
+    (56, 2048, 768, False, False),        # one graph's g|theta|phi projection
+    (1000, 2304, 260, False, True),       # ragged M / N
+])
+def test_streamk_partial_tiles_combined_by_last_arriver(dev, m, k, n_out, gather, res):
+    """Same for the stream-K remainder of the fp32 GEMM engine (gemm_streamk_kernel): in-kernel combine (bit 0) vs the
+    streamk_fixup_kernel launch (default), vs torch on the CPU, and bitwise determinism over 6 runs."""
+    from relpose_gnn_amd import ops
+    g = torch.Generator().manual_seed(900 + m)
+    w = torch.randn(n_out, k, generator=g) * (1.0 / k) ** 0.5
+    b = torch.randn(n_out, generator=g) * 0.1
+    r = torch.randn(m, n_out, generator=g) if res else None
+    if gather:
+        rows = 64
+        a = torch.randn(rows, k // 3, generator=g)
+        idx = [torch.randint(0, rows, (m,), generator=g) for _ in range(3)]
+        ref = torch.cat([a[i] for i in idx], 1) @ w.t() + b
+        src = [(a.to(dev), i.to(dev)) for i in idx]
+    else:
+        a = torch.randn(m, k, generator=g)
+        ref = a @ w.t() + b
+        src = [(a.to(dev), None)]
+    ref = F.relu(ref + r) if res else ref
+    wd, bd, rd = w.to(dev), b.to(dev), None if r is None else r.to(dev)
+    run = lambda: ops.linear_gather(src, wd, bd, m, residual=rd, relu=res)
+    y_launch = _with_fixup_mode(0, run)
+    ys = [_with_fixup_mode(1, run) for _ in range(6)]
+    assert rel_err(y_launch.cpu(), ref) < 1e-5
+    assert all(torch.equal(y, ys[0]) for y in ys[1:]), "not deterministic"
+    assert rel_err(ys[0], y_launch) < 1e-6 and rel_err(ys[0].cpu(), ref) < 1e-5
