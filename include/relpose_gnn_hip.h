@@ -324,6 +324,9 @@ int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
                                      arrival counter in the scratch block, agent-scope slab stores / loads, slabs summed in ascending k order:
                                      same bits whoever comes last) instead of by a separate fix-up launch.  Bit 0: stream-K tiles of the fp32 GEMM
                                      engine; bit 1: Winograd tail tiles of up to 8 parts (wino43_conv8_kernel only); + 4: up to 32 parts */
+#define RPG_TUNE_BF16_CHUNK 21     /* bf16 encoder: runs of identity blocks on activation tensors of >= M MB are walked depth-first, `value & 4095`
+                                     images at a time (their intermediates then come back from the Infinity Cache instead of HBM); M = value >> 12
+                                     (0: 64 MB); 0 = off */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

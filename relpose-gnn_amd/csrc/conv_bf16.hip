@@ -906,6 +906,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
 }
 
 int g_bf16_fused_stem = 1;   // RPG_TUNE_FUSED_STEM also selects the bf16 encoder's fused stem (stem_bf16.hip)
+int g_bf16_chunk = 0;        // RPG_TUNE_BF16_CHUNK: images per depth-first group of the bf16 encoder's identity-block runs (0 = off)
+int g_bf16_chunk_mb = 64;    // ... for activation tensors of at least this many MB
 int g_bf16_dma = 1;      // RPG_TUNE_BF16_DMA: 0 off | 1 by shape | 10 + i: configuration i of launch_dma_config wherever it is eligible
 int g_bf16_tile = -1;    // RPG_TUNE_BF16_TILE: -1 auto | 0: 64x64 | 1: 128x128 | 2: 256x64 | 3: 128x64 (interleaved kernel only)
 int g_bf16_fast = 1;     // RPG_TUNE_BF16_FAST: the interleaved buffer-load kernel where eligible
@@ -1103,6 +1105,7 @@ void bf16_set_tile(int t) { g_bf16_tile = t; }
 void bf16_set_dma(int v) { g_bf16_dma = v; }
 void bf16_set_patch(int v) { g_bf16_stages = v >= 10 ? 3 : 4; g_bf16_patch = v % 10; }
 void bf16_set_fused_stem(int on) { g_bf16_fused_stem = on; }
+void bf16_set_chunk(int images, int min_mb) { g_bf16_chunk = images; g_bf16_chunk_mb = min_mb; }
 #ifdef RPG_PROBE_WS64
 int bf16_set_ws64(int v) { g_bf16_ws64 = v; return RPG_OK; }
 #else
@@ -1373,6 +1376,39 @@ static int resnet_forward_bf16_impl(const void* const* tensors, int n_tensors, c
             const int c = planes[l];
             const bool ds = (stride != 1 || cin != c);
             const int ho = conv_out(hh, 3, stride, 1), wo = conv_out(ww, 3, stride, 1);
+            // Depth-first over image groups (round 4, RPG_TUNE_BF16_CHUNK): a run of identity blocks (stride 1, no downsample)
+            // on LARGE activation tensors is walked group of images by group of images -- conv1, conv2 of every block of the
+            // run on `g_bf16_chunk` images, then the next group -- so that a group's intermediate tensors (and the residual) are
+            // re-read from the 256-MB Infinity Cache instead of HBM.  Images are independent: same kernels, same arithmetic,
+            // only the pointers and the image count of a launch change.
+            const size_t act_bytes = (size_t)n * hh * ww * c * 2;
+            if (!ds && g_bf16_chunk > 0 && n > g_bf16_chunk && act_bytes >= ((size_t)g_bf16_chunk_mb << 20)) {
+                int run = 1;                                   // identity blocks b .. b + run - 1 (all that follow in this layer)
+                while (b + run < blocks[l]) ++run;
+                const size_t img = (size_t)hh * ww * c * 2;    // bytes per image of every tensor in the run
+                for (int i0 = 0; i0 < n; i0 += g_bf16_chunk) {
+                    const int ni = n - i0 < g_bf16_chunk ? n - i0 : g_bf16_chunk;
+                    int cc = cur, tj = ti;
+                    for (int r = 0; r < run; ++r) {
+                        char* X = static_cast<char*>(buf[cc]) + i0 * img;
+                        char* T = static_cast<char*>(buf[(cc + 1) & 3]) + i0 * img;
+                        char* Y = static_cast<char*>(buf[(cc + 2) & 3]) + i0 * img;
+                        if ((rc = rpg::launch_conv_bf16(X, tensors[tj], (const float*)tensors[tj + 1], (const float*)tensors[tj + 2],
+                                                        nullptr, T, ni, hh, ww, c, c, 3, 3, 1, 1, 1, 0, s)) != RPG_OK)
+                            return rc;
+                        if ((rc = rpg::launch_conv_bf16(T, tensors[tj + 3], (const float*)tensors[tj + 4], (const float*)tensors[tj + 5],
+                                                        X, Y, ni, hh, ww, c, c, 3, 3, 1, 1, 1, 0, s)) != RPG_OK)
+                            return rc;
+                        tj += 6;
+                        cc = (cc + 2) & 3;
+                    }
+                }
+                ti += 6 * run;
+                cur = (cur + 2 * run) & 3;
+                b += run - 1;
+                cin = c;
+                continue;
+            }
             void* X = buf[cur];
             void* T = buf[(cur + 1) & 3];
             void* Y = buf[(cur + 2) & 3];
