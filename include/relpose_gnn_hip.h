@@ -67,8 +67,11 @@ int rpg_conv2d_bn_act_nhwc_f32(const float* x, const float* w_ohwi, const float*
                                int kh, int kw, int stride, int pad, int relu, void* stream);
 
 /* The same op for the 3x3 / stride 1 / pad 1 case as a 1-D Winograd F(4,3) along the width: half the f32 MFMA work.
- *   u  [6][cout][3][cin]   transformed weights from rpg_wino43_transform_weights_f32 (once per weight load)
+ *   u  [6][cout][3][cin]   transformed weights from rpg_wino43_transform_weights_f32 (once per weight load);
+ *      rpg_wino43_weights_floats(cout, cin) floats = 18 * cout * cin (42 * cout * cin in a probe build that carries the nested
+ *      F(4x2, 3x3) experiment of round 4, tools/probes/winograd2d.hip: its image [24][cout][cin] follows the 1-D one)
  *   cin % 4 == 0, cout % 4 == 0; x [n][h][w][cin] -> y [n][h][w][cout]; other arguments as above.            */
+size_t rpg_wino43_weights_floats(int cout, int cin);
 int rpg_wino43_transform_weights_f32(const float* w_ohwi /* [cout][3][3][cin] */, float* u, int cout, int cin,
                                      void* stream);
 int rpg_conv3x3_wino43_bn_act_nhwc_f32(const float* x, const float* u, const float* scale, const float* shift,
@@ -327,6 +330,9 @@ int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
 #define RPG_TUNE_BF16_CHUNK 21     /* bf16 encoder: runs of identity blocks on activation tensors of >= M MB are walked depth-first, `value & 4095`
                                      images at a time (their intermediates then come back from the Infinity Cache instead of HBM); M = value >> 12
                                      (0: 64 MB); 0 = off */
+#define RPG_TUNE_WINO2D 22         /* probe builds only (-DRPG_PROBE_WINO2D: the nested 2-D Winograd F(4x2, 3x3) kernel, 3 instead of 4.5 multiplies per
+                                     output -- correct and 13-34 % slower, profiles/r4_wino2d_nested_kernel.txt): 1 by shape | 2 wherever
+                                     eligible.  The product library accepts 0 and returns RPG_ERR_BAD_ARG for anything else */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

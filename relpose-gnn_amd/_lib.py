@@ -22,7 +22,7 @@ SYMBOLS = (
     "rpg_maxpool3x3s2_nhwc_f32", "rpg_global_avgpool_nhwc_f32", "rpg_resnet_workspace_bytes",
     "rpg_resnet_forward_f32", "rpg_graph_prepare", "rpg_edge_concat_gather_f32", "rpg_linear_gather_f32",
     "rpg_attention_rows_f32", "rpg_scatter_mean_f32", "rpg_pose_heads_f32", "rpg_gnn_workspace_bytes",
-    "rpg_gnn_forward_f32", "rpg_timing_enable", "rpg_timing_read", "rpg_set_tuning", "rpg_knn_graph_f32", "rpg_wino43_transform_weights_f32",
+    "rpg_gnn_forward_f32", "rpg_timing_enable", "rpg_timing_read", "rpg_set_tuning", "rpg_knn_graph_f32", "rpg_wino43_transform_weights_f32", "rpg_wino43_weights_floats",
     "rpg_conv3x3_wino43_bn_act_nhwc_f32", "rpg_conv2d_bn_act_nhwc_bf16", "rpg_resnet_bf16_workspace_bytes",
     "rpg_resnet_forward_bf16", "rpg_gnn_forward_bf16", "rpg_f32_to_bf16", "rpg_linear_bf16",
     "rpg_release_scratch", "rpg_timing_read_ex", "rpg_stem_conv7x7s2_bn_relu_maxpool_f32", "rpg_stem_pair_table",
@@ -78,6 +78,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.rpg_resnet_forward_bf16.argtypes = [C.POINTER(_vp), _i, C.POINTER(_i), C.POINTER(_i), _i, _vp, _i, _i, _i, _vp,
                                             _vp, _sz, _vp]
     lib.rpg_wino43_transform_weights_f32.argtypes = [_vp, _vp, _i, _i, _vp]
+    lib.rpg_wino43_weights_floats.argtypes = [_i, _i]
+    lib.rpg_wino43_weights_floats.restype = C.c_size_t
     lib.rpg_conv3x3_wino43_bn_act_nhwc_f32.argtypes = [_vp] * 6 + [_i] * 6 + [_vp]
     lib.rpg_knn_graph_f32.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.rpg_timing_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
@@ -96,6 +98,15 @@ def _declare(lib: C.CDLL) -> None:
 
 def lib() -> C.CDLL:
     """Load (once) and return the shared library; raises HipLibraryMissing if it has not been built."""
+    global _lib
+    if _lib is None:
+        # RPG_LIB_PATH: a diagnostic build of the same library (ablation / trace variants made by tools/probes/*.sh)
+        path = os.environ.get("RPG_LIB_PATH") or LIB_PATH
+        return _load(path)
+    return _lib
+
+
+def _load(LIB_PATH: str) -> C.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):

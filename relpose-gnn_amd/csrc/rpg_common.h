@@ -109,6 +109,13 @@ bool wino_enabled();
 // addressable, and large enough that the un-split K loop is not latency-bound)
 bool wino_pays(int n, int h, int w, int cin, int cout);
 void wino_set(int on);
+// nested 2-D Winograd F(4x2, 3x3) (csrc/winograd2d.hip)
+void wino2d_set(int v);
+size_t wino_weight_floats(int cout, int cin);
+int launch_wino2d_weights(const float* w_ohwi, float* u2, int cout, int cin, hipStream_t s);
+bool wino2d_takes(int n, int h, int w, int cin, int cout);
+int launch_conv_wino2d(const float* x, const float* u2, const float* scale, const float* shift, const float* residual, float* y,
+                       int n, int h, int w, int cin, int cout, int relu, hipStream_t s);
 void stem_pool_set(int on);
 void wino_split_set(int on);
 void wino_short_set(int cin);

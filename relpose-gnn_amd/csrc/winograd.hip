@@ -1159,8 +1159,15 @@ int g_wino_combine_max = 8;              // most parts of a tail tile that its l
 
 }  // namespace
 
+#ifdef RPG_PROBE_WINO2D
+#include "../../tools/probes/winograd2d.hip"      // the nested F(4x2, 3x3) experiment of round 4 (correct, slower): opt-in
+#endif
+
 namespace rpg {
 
+#ifndef RPG_PROBE_WINO2D
+void wino2d_set(int) {}                           // RPG_TUNE_WINO2D is accepted (0) and ignored in a build without the probe kernel
+#endif
 bool wino_enabled() { return g_wino != 0; }
 void wino_set(int on) { g_wino = on; }
 void wino_split_set(int v) { g_wino_split = v != 0; g_wino_split_steps = v >= 2 ? v : 3; }
@@ -1187,6 +1194,12 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
         !aligned16(x) || !aligned16(u) || !aligned16(y) || (scale && !aligned16(scale)) || (shift && !aligned16(shift)) ||
         (residual && !aligned16(residual)))
         return RPG_ERR_BAD_ARG;
+#ifdef RPG_PROBE_WINO2D
+    // probe builds: the nested 2-D form F(4x2, 3x3) (tools/probes/winograd2d.hip) where RPG_TUNE_WINO2D selects it; its weights
+    // follow the 1-D image in the same buffer
+    if (wino2d_takes(n, h, w, cin, cout))
+        return launch_conv_wino2d(x, u + (size_t)18 * cout * cin, scale, shift, residual, y, n, h, w, cin, cout, relu, s);
+#endif
     const int tw = (w + 3) / 4;
     const long M = (long)n * h * tw;
     // 32-bit buffer offsets: a workgroup's 64 tiles span at most 65 images (+ 3 rows of scalar offset); U is
@@ -1288,13 +1301,28 @@ extern "C" int rpg_wino_trace_set(unsigned long long* buf) {
 }
 #endif
 
+// floats of the transformed-weight buffer of one convolution: U [6][cout][3][cin] (+ the nested image [24][cout][cin] behind it
+// in a probe build with the 2-D kernel, tools/probes/winograd2d.hip)
+extern "C" size_t rpg_wino43_weights_floats(int cout, int cin) {
+    if (cout <= 0 || cin <= 0) return 0;
+#ifdef RPG_PROBE_WINO2D
+    return rpg::wino_weight_floats(cout, cin);
+#else
+    return (size_t)18 * cout * cin;
+#endif
+}
+
 extern "C" int rpg_wino43_transform_weights_f32(const float* w_ohwi, float* u, int cout, int cin, void* stream) {
     if (!w_ohwi || !u || cout <= 0 || cin <= 0) return RPG_ERR_BAD_ARG;
     const long total = (long)cout * 3 * cin;
     hipLaunchKernelGGL(wino43_weights_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, rpg::as_stream(stream),
                        w_ohwi, u, cout, cin, total);
     RPG_CHECK_LAUNCH("wino43_transform_weights");
+#ifdef RPG_PROBE_WINO2D
+    return rpg::launch_wino2d_weights(w_ohwi, u + (size_t)18 * cout * cin, cout, cin, rpg::as_stream(stream));
+#else
     return RPG_OK;
+#endif
 }
 
 extern "C" int rpg_conv3x3_wino43_bn_act_nhwc_f32(const float* x, const float* u, const float* scale, const float* shift,

@@ -62,12 +62,13 @@ def conv2d_bn_act_nhwc(x: torch.Tensor, w_ohwi: torch.Tensor, scale: Optional[to
 
 
 def wino43_transform_weights(w_ohwi: torch.Tensor) -> torch.Tensor:
-    """[Cout][3][3][Cin] -> Winograd F(4,3) weights U [6][Cout][3][Cin] (once per weight load)."""
+    """[Cout][3][3][Cin] -> Winograd F(4,3) weights U [6][Cout][3][Cin] (once per weight load), as one flat buffer of
+    rpg_wino43_weights_floats(Cout, Cin) floats (18 Cout Cin; a probe build with the nested 2-D kernel appends its image)."""
     w_ohwi = _req(w_ohwi, "w_ohwi")
     cout, kh, kw, cin = w_ohwi.shape
     if (kh, kw) != (3, 3):
         raise ValueError("Winograd F(4,3) path is for 3x3 kernels")
-    u = torch.empty((6, cout, 3, cin), dtype=torch.float32, device=w_ohwi.device)
+    u = torch.empty((int(L.lib().rpg_wino43_weights_floats(cout, cin)),), dtype=torch.float32, device=w_ohwi.device)
     L.check(L.lib().rpg_wino43_transform_weights_f32(_p(w_ohwi), _p(u), cout, cin, _stream()), "wino43_transform_weights")
     return u
 
@@ -76,9 +77,10 @@ def conv3x3_wino43_bn_act_nhwc(x: torch.Tensor, u: torch.Tensor, scale: Optional
                                residual: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
     x, u = _req(x, "x"), _req(u, "u")
     n, h, w, cin = x.shape
-    if u.dim() != 4 or u.shape[0] != 6 or u.shape[2] != 3 or u.shape[3] != cin:
-        raise ValueError("u must be [6][Cout][3][Cin]")
-    cout = u.shape[1]
+    per = int(L.lib().rpg_wino43_weights_floats(1, 1))            # 18 (42 in a probe build with the nested kernel)
+    if u.dim() != 1 or u.numel() == 0 or u.numel() % (per * cin):
+        raise ValueError("u must be the flat buffer of wino43_transform_weights")
+    cout = u.numel() // (per * cin)
     y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
     scale = None if scale is None else _req(scale, "scale")
     shift = None if shift is None else _req(shift, "shift")
@@ -312,7 +314,7 @@ def release_scratch() -> None:
     L.check(L.lib().rpg_release_scratch(), "release_scratch")
 
 
-TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST, TUNE_FUSED_STEM, TUNE_WAVES8, TUNE_WINO_SHORT, TUNE_GNN_FUSE_AGG, TUNE_WINO_PERSIST, TUNE_BF16_TILE, TUNE_BF16_DMA, TUNE_BF16_PATCH, TUNE_BF16_WS64, TUNE_SK_MIN_ITS, TUNE_INKERNEL_FIXUP, TUNE_BF16_CHUNK = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21
+TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST, TUNE_FUSED_STEM, TUNE_WAVES8, TUNE_WINO_SHORT, TUNE_GNN_FUSE_AGG, TUNE_WINO_PERSIST, TUNE_BF16_TILE, TUNE_BF16_DMA, TUNE_BF16_PATCH, TUNE_BF16_WS64, TUNE_SK_MIN_ITS, TUNE_INKERNEL_FIXUP, TUNE_BF16_CHUNK, TUNE_WINO2D = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22
 
 
 def set_tuning(key: int, value: int) -> None:

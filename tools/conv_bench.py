@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--tile", type=int, default=-1)
     ap.add_argument("--sk", type=int, default=1)
     ap.add_argument("--wino", type=int, default=1)
+    ap.add_argument("--wino2d-ab", action="store_true", help="fp32 3x3/s1 shapes: time the 1-D F(4,3) and the nested F(4x2,3x3) kernels interleaved")
     ap.add_argument("--nimg", type=int, default=256, help="images in the batch (256 = 32 graphs)")
     ap.add_argument("--warm", type=int, default=0, help="untimed launches before the timed ones")
     ap.add_argument("--bf16", action="store_true", help="the bf16 convolution kernels (bf16 activations / weights) instead of fp32")
@@ -129,6 +130,21 @@ def main():
                 print(f"conv {name:6s} M={n*ho*wo:8d} N={cout:4d} K={k*k*cin:5d}  " + "  ".join(cells), flush=True)
                 continue
             med, best = timeit(run, args.reps)
+        elif args.wino and k == 3 and s == 1 and args.wino2d_ab:
+            # A/B of the two Winograd forms on the same operands, interleaved in one process: 1-D F(4,3) (RPG_TUNE_WINO2D = 0)
+            # against the nested F(4x2, 3x3) (= 2), + their relative max-norm difference
+            u = ops.wino43_transform_weights(wt)
+            fl = 2.0 * n * ho * wo * cout * 9 * cin
+            cells, outs = [], {}
+            for mode in (0, 2, 0, 2):
+                ops.set_tuning(ops.TUNE_WINO2D, mode)
+                med, best = timeit(lambda: ops.conv3x3_wino43_bn_act_nhwc(x, u, sc, sh, r, relu=True), args.reps)
+                outs[mode] = ops.conv3x3_wino43_bn_act_nhwc(x, u, sc, sh, r, relu=True)
+                cells.append(f"{'1-D' if mode == 0 else 'nested'}:{med*1e3:7.1f}us/{fl/med/1e9:6.1f}TF")
+            ops.set_tuning(ops.TUNE_WINO2D, 1)
+            diff = float((outs[2] - outs[0]).abs().max() / outs[0].abs().max())
+            print(f"conv {name:6s} M={n*ho*wo:8d} N={cout:4d} K={9*cin:5d}  " + "  ".join(cells) + f"  |nested - 1-D| = {diff:.2e}", flush=True)
+            continue
         elif args.wino and k == 3 and s == 1:
             u = ops.wino43_transform_weights(wt)
             name = name + "w"
