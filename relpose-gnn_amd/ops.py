@@ -68,7 +68,10 @@ def wino43_transform_weights(w_ohwi: torch.Tensor) -> torch.Tensor:
     cout, kh, kw, cin = w_ohwi.shape
     if (kh, kw) != (3, 3):
         raise ValueError("Winograd F(4,3) path is for 3x3 kernels")
-    u = torch.empty((int(L.lib().rpg_wino43_weights_floats(cout, cin)),), dtype=torch.float32, device=w_ohwi.device)
+    floats = int(L.lib().rpg_wino43_weights_floats(cout, cin))
+    # [6][Cout][3][Cin] in the product build; a flat buffer when a probe build appends the nested 2-D image behind it
+    shape = (6, cout, 3, cin) if floats == 18 * cout * cin else (floats,)
+    u = torch.empty(shape, dtype=torch.float32, device=w_ohwi.device)
     L.check(L.lib().rpg_wino43_transform_weights_f32(_p(w_ohwi), _p(u), cout, cin, _stream()), "wino43_transform_weights")
     return u
 
@@ -78,8 +81,8 @@ def conv3x3_wino43_bn_act_nhwc(x: torch.Tensor, u: torch.Tensor, scale: Optional
     x, u = _req(x, "x"), _req(u, "u")
     n, h, w, cin = x.shape
     per = int(L.lib().rpg_wino43_weights_floats(1, 1))            # 18 (42 in a probe build with the nested kernel)
-    if u.dim() != 1 or u.numel() == 0 or u.numel() % (per * cin):
-        raise ValueError("u must be the flat buffer of wino43_transform_weights")
+    if u.dim() not in (1, 4) or u.numel() == 0 or u.numel() % (per * cin) or (u.dim() == 4 and tuple(u.shape[::2]) != (6, 3)):
+        raise ValueError("u must come from wino43_transform_weights: [6][Cout][3][Cin]")
     cout = u.numel() // (per * cin)
     y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
     scale = None if scale is None else _req(scale, "scale")

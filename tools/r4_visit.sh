@@ -9,7 +9,7 @@ for step in "$@"; do
   case $step in
     tests)
       rm -f gpurun_out/parity_report.jsonl
-      timeout 3000 python -m pytest tests -q -m gpu -x > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest.log"
+      timeout 3000 python -m pytest tests -q -m gpu > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest.log"
       tail -25 "$OUT/pytest.log"; cp gpurun_out/parity_report.jsonl "$OUT/" 2>/dev/null;;
     newtests)
       rm -f gpurun_out/parity_report.jsonl
