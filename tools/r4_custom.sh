@@ -1,9 +1,11 @@
 #!/bin/bash
 OUT=$1
 cd "${GRAFT_REPO_ROOT:-.}"
-# exact-round geometry for the nested kernel (no tile-quantisation loss): layer 3 at 512 images = 1792 workgroups = 7 rounds,
-# layer 2 at 512 images = 3136 = 12.25 rounds, layer 1 at 256 = 3136
-for n in 512 256; do
-  echo "== images $n"
-  timeout 600 python tools/conv_bench.py --nimg $n --warm 3 --reps 10 --only "c1" --wino2d-ab 2>&1 | grep "^conv" | cut -c1-175
-done | tee "$OUT/wino2d_ab_exact_rounds.txt"
+for st in 0 100 200 400 800 0; do
+  echo "== stagger $st ticks (10 ns)"
+  for mode in 1 2; do
+    timeout 300 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --reps 10 --only "l1.c" --tune 17=$mode --tune 23=$st 2>&1 | grep "^conv" | sed "s/^/patch$mode /"
+  done
+  timeout 300 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --reps 10 --only "l2.c" --tune 23=$st 2>&1 | grep "^conv"
+  timeout 300 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --reps 10 --only "l3.c1" --tune 23=$st 2>&1 | grep "^conv"
+done | tee "$OUT/stagger.txt"
