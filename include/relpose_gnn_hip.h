@@ -333,6 +333,9 @@ int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
 #define RPG_TUNE_WINO2D 22         /* probe builds only (-DRPG_PROBE_WINO2D: the nested 2-D Winograd F(4x2, 3x3) kernel, 3 instead of 4.5 multiplies per
                                      output -- correct and 13-34 % slower, profiles/r4_wino2d_nested_kernel.txt): 1 by shape | 2 wherever
                                      eligible.  The product library accepts 0 and returns RPG_ERR_BAD_ARG for anything else */
+#define RPG_TUNE_BF16_LEAN_EPI 23   /* bf16 convolutions (bf16 output, optional bf16 residual): 1 (default) the branch-free epilogue of round 4 (raw buffer
+                                     accesses with out-of-range offsets instead of a branch per row, 32-bit offsets, residual as a template
+                                     parameter: -7..-12 % on the convolution kernels) | 0: the general epilogue of rounds 1-3 */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

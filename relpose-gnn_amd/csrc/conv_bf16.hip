@@ -42,6 +42,9 @@ struct EpiB {
     __bf16* out2 = nullptr;
     int ld2 = 0;
     int relu2 = 0;
+    // set by the launcher: the plain convolution case (bf16 output, optional bf16 residual, none of the fp32 / second-output
+    // options, N % 4 == 0, a workgroup's rows addressable with 32-bit byte offsets) -> bf16_tile_epilogue_lean_body
+    int lean = 0;
 };
 
 struct ConvArgsB {
@@ -134,6 +137,91 @@ __device__ __forceinline__ void bf16_tile_epilogue(f32x16 (&acc)[FM][FN], unsign
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int t = 0; t < NIT; ++t) rs_cur[t] = rs_nxt[t];
+    }
+}
+
+// The same epilogue for the plain convolution case (ep.lean), written for instruction count (round 4).  Measured with the
+// epilogue compiled out of the patch kernel (tools/probes/patch_ablate.sh): the general version above costs 6.6 us of a 19-us
+// 512 x 64 tile, 8.5 us of a 256 x 256 tile -- not memory time (de-phasing the workgroups changes nothing) but ~2,400 instructions
+// per wave: a branch per row and option (131 s_cbranch), 64-bit address arithmetic per access (208 v_lshl_add_u64, 96 v_mad_u64),
+// SGPR spills (156 v_readlane) and a conservative wait per region.  Here: raw buffer accesses based at the wave's first row
+// (invalid rows / columns carry an out-of-range offset: loads return zero, stores are dropped -- no branches), 32-bit offsets
+// built incrementally, the residual rows of a fragment requested one fragment ahead, the residual as a template parameter.
+typedef unsigned int u32x2e __attribute__((ext_vector_type(2)));
+template <int FM, int FN, int NWAVES, bool RES>
+__device__ __forceinline__ void bf16_tile_epilogue_lean_body(f32x16 (&acc)[FM][FN], unsigned char* lds_raw, const EpiB& ep, int m0,
+                                                             int n0, int M, int N, int wm, int wn, int lane, int wave) {
+    constexpr int EW = FN * 32, EPITCH = EW + 4, C4 = EW / 4, RPI = 64 / C4, NIT = 32 / RPI;
+    constexpr unsigned OOB = 0x80000000u;
+    float* slab = reinterpret_cast<float*>(lds_raw) + wave * (32 * EPITCH);
+    const int c4 = lane % C4, r_in = lane / C4;
+    const int nb = n0 + wn * EW + 4 * c4;
+    const bool n_ok = nb < N;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n_ok && ep.scale) sc = *reinterpret_cast<const float4*>(ep.scale + nb);
+    if (n_ok && ep.shift) sh = *reinterpret_cast<const float4*>(ep.shift + nb);
+    const int mw = m0 + wm * FM * 32;                        // first row of this wave (wave-uniform)
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<__bf16*>(ep.out) + (size_t)mw * ep.ldc, 0,
+                                                                         0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(RES ? ep.residual : reinterpret_cast<const __bf16*>(ep.out)) + (size_t)mw * ep.ldc, 0, 0x7fffffff, 0x00020000);
+    const unsigned row_b = 2u * (unsigned)ep.ldc;             // bytes per output row
+    const unsigned base = n_ok ? (unsigned)r_in * row_b + 2u * (unsigned)nb : OOB;      // row r_in of fragment 0
+    const int rows_left = M - mw;                             // rows of this wave's range that exist (may be <= 0)
+    const float floor_v = ep.relu ? 0.f : -INFINITY;
+    auto off = [&](int i, int t) -> unsigned {
+        const int r = i * 32 + r_in + RPI * t;
+        return (n_ok && r < rows_left) ? base + (unsigned)(i * 32 + RPI * t) * row_b : OOB;
+    };
+    u32x2e rs_cur[NIT], rs_nxt[NIT];
+    auto load_res = [&](int i, u32x2e (&dst)[NIT]) {
+        if (!RES) return;
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) dst[t] = __builtin_bit_cast(u32x2e, __builtin_amdgcn_raw_buffer_load_b64(rr, off(i, t), 0, 0));
+    };
+    load_res(0, rs_cur);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        if (i + 1 < FM) load_res(i + 1, rs_nxt);
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                slab[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * EPITCH + j * 32 + (lane & 31)] = acc[i][j][e];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(&slab[(r_in + RPI * t) * EPITCH + 4 * c4]);
+            float4 y;
+            y.x = v.x * sc.x + sh.x; y.y = v.y * sc.y + sh.y; y.z = v.z * sc.z + sh.z; y.w = v.w * sc.w + sh.w;
+            if (RES) {
+                const bf16x4 rs = __builtin_bit_cast(bf16x4, rs_cur[t]);
+                y.x += (float)rs[0]; y.y += (float)rs[1]; y.z += (float)rs[2]; y.w += (float)rs[3];
+            }
+            const bf16x4 ob = {(__bf16)fmaxf(y.x, floor_v), (__bf16)fmaxf(y.y, floor_v), (__bf16)fmaxf(y.z, floor_v), (__bf16)fmaxf(y.w, floor_v)};
+#if defined(RPG_PATCH_ABL) && (RPG_PATCH_ABL & 4)      // diagnostic: all stores of the wave land in one 64-KB window (L2-resident): the
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2e, ob), ro, off(i, t) & 0xffffu, 0, 0);      // epilogue without its HBM writes
+#else
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2e, ob), ro, off(i, t), 0, 0);
+#endif
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (RES) {
+#pragma unroll
+            for (int t = 0; t < NIT; ++t) rs_cur[t] = rs_nxt[t];
+        }
+    }
+}
+
+// dispatch: the lean form for plain convolutions, the general one otherwise (both forms live in every kernel; `lean` is uniform)
+template <int FM, int FN, int SLAB_BUDGET_BYTES, int NWAVES = 4>
+__device__ __forceinline__ void bf16_tile_epilogue_any(f32x16 (&acc)[FM][FN], unsigned char* lds_raw, const EpiB& ep, int m0,
+                                                       int n0, int M, int N, int wm, int wn, int lane, int wave) {
+    if (ep.lean) {
+        if (ep.residual) bf16_tile_epilogue_lean_body<FM, FN, NWAVES, true>(acc, lds_raw, ep, m0, n0, M, N, wm, wn, lane, wave);
+        else bf16_tile_epilogue_lean_body<FM, FN, NWAVES, false>(acc, lds_raw, ep, m0, n0, M, N, wm, wn, lane, wave);
+    } else {
+        bf16_tile_epilogue<FM, FN, SLAB_BUDGET_BYTES, NWAVES>(acc, lds_raw, ep, m0, n0, M, N, wm, wn, lane, wave);
     }
 }
 
@@ -633,7 +721,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the zero pieces of the steps past K: LDS becomes the epilogue slabs
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    bf16_tile_epilogue<FM, FN, ST * IMG_B, NW>(acc, lds_raw, ep, m0, n0, M, N, wm, wn, lane, wave);
+    bf16_tile_epilogue_any<FM, FN, ST * IMG_B, NW>(acc, lds_raw, ep, m0, n0, M, N, wm, wn, lane, wave);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -916,9 +1004,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
         if (sacc == 123.456f) reinterpret_cast<__bf16*>(ep.out)[tid] = (__bf16)sacc;
         return;
     }
-    bf16_tile_epilogue<FM, FN, 160 * 1024, NW>(acc, lds_raw, ep, m0, n0, a.M, a.N, wm, wn, lane, wave);
+    bf16_tile_epilogue_any<FM, FN, 160 * 1024, NW>(acc, lds_raw, ep, m0, n0, a.M, a.N, wm, wn, lane, wave);
 }
 
+int g_bf16_lean_epi = 1;     // RPG_TUNE_BF16_LEAN_EPI: the branch-free epilogue for plain convolutions (0: the general one, rounds 1-3)
 int g_bf16_fused_stem = 1;   // RPG_TUNE_FUSED_STEM also selects the bf16 encoder's fused stem (stem_bf16.hip)
 int g_bf16_chunk = 0;        // RPG_TUNE_BF16_CHUNK: images per depth-first group of the bf16 encoder's identity-block runs (0 = off)
 int g_bf16_chunk_mb = 64;    // ... for activation tensors of at least this many MB
@@ -1119,6 +1208,7 @@ void bf16_set_tile(int t) { g_bf16_tile = t; }
 void bf16_set_dma(int v) { g_bf16_dma = v; }
 void bf16_set_patch(int v) { g_bf16_stages = v >= 10 ? 3 : 4; g_bf16_patch = v % 10; }
 void bf16_set_fused_stem(int on) { g_bf16_fused_stem = on; }
+void bf16_set_lean_epi(int on) { g_bf16_lean_epi = on; }
 void bf16_set_chunk(int images, int min_mb) { g_bf16_chunk = images; g_bf16_chunk_mb = min_mb; }
 #ifdef RPG_PROBE_WS64
 int bf16_set_ws64(int v) { g_bf16_ws64 = v; return RPG_OK; }
@@ -1205,6 +1295,8 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
     if (M >= (1L << 31) || K >= (1 << 24) || (long)h * wd * cin >= (1L << 31)) return RPG_ERR_BAD_ARG;
     ConvArgsB a{reinterpret_cast<const __bf16*>(x), h, wd, cin, kh, kw, stride, pad, ho, wo};
     EpiB ep{scale, shift, reinterpret_cast<const __bf16*>(residual), y, cout, relu, out_f32};
+    // plain convolution: the lean epilogue (RPG_TUNE_BF16_LEAN_EPI); a workgroup's <= 1024 rows within 32-bit byte offsets
+    ep.lean = g_bf16_lean_epi && !out_f32 && (cout & 3) == 0 && 1024L * cout * 2 < (1L << 31);
     const __bf16* wp = reinterpret_cast<const __bf16*>(w);
     const int slot = timing_begin(RPG_TIMER_CONV, s);
     const bool big_k = g_bf16_bk == 64 && K >= 128;

@@ -241,6 +241,47 @@ def test_conv3x3_bf16_patch_kernel(dev, mode, n, h, w, cin, cout, res, relu):
     assert float((got - ref).abs().mean() / ref.abs().mean().clamp(min=1e-30)) < 3e-3     # bf16 output rounding only
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,k,stride,pad,res", [
+    (100, 56, 56, 64, 64, 3, 1, 1, True),       # layer 1 at 100 images: LDS-DMA kernel 256 x 64 (two workgroups per CU), ragged last tile
+    (24, 28, 28, 128, 128, 3, 1, 1, True),      # layer 2: patch kernel 512 x 128
+    (40, 14, 14, 256, 256, 3, 1, 1, False),     # layer 3: patch kernel 256 x 256, tiles span images
+    (70, 7, 7, 512, 512, 3, 1, 1, True),        # layer 4
+    (24, 56, 56, 64, 128, 3, 2, 1, False),      # 3x3 / stride 2
+    (24, 56, 56, 64, 128, 1, 2, 0, False),      # 1x1 / stride 2 downsample (no ReLU in the model; here with)
+    (3, 13, 17, 192, 72, 3, 1, 1, True),        # ragged N (72 = 2 x 32 + 8), odd sizes
+    (5, 8, 11, 64, 320, 3, 1, 1, True),         # two channel tiles, the second ragged
+])
+def test_conv_bf16_lean_epilogue_equals_general(dev, n, h, w, cin, cout, k, stride, pad, res):
+    """The branch-free epilogue of the plain bf16 convolutions (round 4, RPG_TUNE_BF16_LEAN_EPI = 1: raw buffer accesses with
+    out-of-range offsets for invalid rows / columns, 32-bit offsets, residual as a template parameter) against the general
+    epilogue of rounds 1-3 (= 0) on the same operands: the same arithmetic in the same order, so the bf16 outputs agree
+    bit for bit; and both within the bf16 bar of F.conv2d.  Every kernel family that reaches it: LDS-DMA, patch, ragged tiles."""
+    from relpose_gnn_amd import ops
+    x = _rand(n, cin, h, w, seed=61).bfloat16()
+    wt = _rand(cout, cin, k, k, seed=62, scale=(2.0 / (cin * k * k)) ** 0.5).bfloat16()
+    scale = torch.rand(cout, generator=torch.Generator().manual_seed(63)) + 0.5
+    shift = _rand(cout, seed=64, scale=0.1)
+    ref = F.conv2d(x.float(), wt.float(), None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    r = None
+    if res:
+        r = _rand(*ref.shape, seed=65).bfloat16()
+        ref = ref + r.float()
+    ref = F.relu(ref)
+    xd, wd = x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev)
+    rd = None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev)
+    outs = {}
+    try:
+        for lean in (1, 0):
+            ops.set_tuning(ops.TUNE_BF16_LEAN_EPI, lean)
+            outs[lean] = ops.conv2d_bn_act_nhwc_bf16(xd, wd, scale.to(dev), shift.to(dev), rd, stride=stride, pad=pad, relu=True)
+    finally:
+        ops.set_tuning(ops.TUNE_BF16_LEAN_EPI, 1)
+    assert torch.equal(outs[1], outs[0])
+    got = outs[1].float().cpu().permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < 1e-2
+    assert float((got - ref).abs().mean() / ref.abs().mean().clamp(min=1e-30)) < 3e-3
+
+
 @pytest.mark.parametrize("n,h,w", [(2, 224, 224), (1, 256, 341), (3, 37, 53), (2, 9, 5), (1, 64, 500), (5, 32, 40), (1, 1, 1), (70, 64, 72),
                                    (67, 40, 24)])
 def test_fused_stem_bf16(dev, n, h, w):

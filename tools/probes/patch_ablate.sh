@@ -1,5 +1,5 @@
 #!/bin/bash
-# Ablation builds of the bf16 patch kernel (csrc/conv_bf16.hip, RPG_PATCH_ABL: 1 no epilogue | 2 no per-step wait + barrier; wrong
+# Ablation builds of the bf16 patch kernel (csrc/conv_bf16.hip, RPG_PATCH_ABL: 1 no epilogue | 2 no per-step wait + barrier | 4 epilogue stores confined to a 64-KB window; wrong
 # results, timing only).  Build container, repo root:  tools/probes/patch_ablate.sh 1 2 3  -> relpose-gnn_amd/lib/abl_patch_<m>.so
 # GPU box:  RPG_LIB_PATH=$PWD/relpose-gnn_amd/lib/abl_patch_1.so python tools/conv_bench.py --bf16 --nimg 512 --only l1.c --tune 17=2
 set -e

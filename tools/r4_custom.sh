@@ -1,11 +1,8 @@
 #!/bin/bash
 OUT=$1
 cd "${GRAFT_REPO_ROOT:-.}"
-for st in 0 100 200 400 800 0; do
-  echo "== stagger $st ticks (10 ns)"
-  for mode in 1 2; do
-    timeout 300 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --reps 10 --only "l1.c" --tune 17=$mode --tune 23=$st 2>&1 | grep "^conv" | sed "s/^/patch$mode /"
-  done
-  timeout 300 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --reps 10 --only "l2.c" --tune 23=$st 2>&1 | grep "^conv"
-  timeout 300 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --reps 10 --only "l3.c1" --tune 23=$st 2>&1 | grep "^conv"
-done | tee "$OUT/stagger.txt"
+timeout 1200 python -m pytest tests/test_hip_bf16.py tests/test_hip_bench_geometry.py tests/test_hip_eval_geometry.py -q -m gpu -k "bf16" > "$OUT/pytest_bf16.log" 2>&1; echo "pytest rc=$?"; tail -6 "$OUT/pytest_bf16.log"
+for lean in 1 0 1 0; do
+  echo "== lean epilogue $lean: bench --graphs 64 --encoder-dtype bf16 --gnn-dtype bf16"
+  timeout 300 python bench.py --steps 20 --warmup 5 --cpu-baseline-seconds 0 --no-other-configs --graphs 64 --encoder-dtype bf16 --gnn-dtype bf16 --tune 23=$lean 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read()); print(l['value'], l['ms_per_step'], l['roofline']['frac'], l['roofline']['avg_launch_ms'])"
+done | tee "$OUT/lean_bench.txt"
