@@ -1345,10 +1345,12 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
         } else if (cout > 64 && big) {
             done = (g_bf16_stages != 3 && launch_patch<512, 128, 4, 2, 4>(a, wp, n, (int)M, cout, ep, s)) ||
                    launch_patch<512, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s);
-        } else if (g_bf16_patch >= 2) {
-            // 64 output channels (layer 1): measured 232-245 us at 512 images against 205-222 us for the im2col DMA kernel with two
-            // 80-KB workgroups per CU (configuration 5) -- a 512 x 64 tile is 18 short steps behind a 61-KB patch, and with one
-            // workgroup per CU nothing overlaps its prologue / epilogue.  Kept for the tests and experiments (mode 2) only.
+        } else if (g_bf16_patch >= 2 || big) {
+            // 64 output channels (layer 1).  Round 3 measured 232-245 us at 512 images against 205-222 us for the im2col DMA kernel
+            // with two 80-KB workgroups per CU (configuration 5: they hide each other's epilogue) and kept this tile for tests only.
+            // With the lean epilogue of round 4 the order flipped where it matters: 216-223 / 229-239 us (without / with residual)
+            // against 214-215 / 246-248, and the whole configs[2] step gains 2.4 % (12.79 -> 13.10 k graphs/s, two streams:
+            // profiles/r4_bf16_epilogue_experiments.txt) -- a quarter of the L2 -> LDS traffic leaves more of the chip to the other stream.
             done = (g_bf16_stages != 3 && launch_patch<512, 64, 8, 1, 4>(a, wp, n, (int)M, cout, ep, s)) ||
                    launch_patch<512, 64, 8, 1, 3>(a, wp, n, (int)M, cout, ep, s);
         }
