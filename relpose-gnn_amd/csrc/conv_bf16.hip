@@ -748,7 +748,13 @@ struct PatchArgs {
     const __bf16* x;
     int H, W, Cin, Nimg, M, N, tiles_n;
     int P, PR, patch_bytes, n_pieces;      // slots per patch row, patch rows, bytes per patch buffer (multiple of 1 KB), 1-KB pieces
+    // floor(2^32 / d) + 1 for d = P, H + 2, H * W, W: the per-lane divisions of the tile set-up as one v_mul_hi each (exact for
+    // numerator * d < 2^32; every numerator here is a slot, a patch row or a pixel offset inside the tile: < 2^15).  Round 4: the
+    // set-up was ~700 instructions before the first load of a tile went out, three quarters of them hipcc's expansion of 24
+    // integer divisions per lane.
+    unsigned mg_p, mg_hv, mg_hw, mg_w;
 };
+__device__ __forceinline__ int div_magic(int n, unsigned magic) { return (int)__umulhi((unsigned)n, magic); }
 
 __device__ __forceinline__ void dma_piece16_raw(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_byte_off, unsigned char* lds_base,
                                                 unsigned voffset, int soffset) {
@@ -787,9 +793,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
     const int H = a.H, W = a.W, HW = a.H * a.W, P = a.P, HV = a.H + 2;
     const int NC = a.Cin / 32;
 
-    // ---- geometry of the tile: first virtual row of the patch, first image
+    // ---- geometry of the tile: first virtual row of the patch, first image (wave-uniform: two real divisions)
     const int n_first = m0 / HW;
-    const int v0 = n_first * HV + (m0 - n_first * HW) / W;          // = v(m0) - 1: the row above the tile's first pixel
+    const int rem_first = m0 - n_first * HW;                         // pixel of m0 inside its image
+    const int v0 = n_first * HV + rem_first / W;                     // = v(m0) - 1: the row above the tile's first pixel
     const int img = HW * a.Cin;
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x) + (size_t)n_first * img, 0,
                                                                           0x7fffffff, 0x00020000);
@@ -804,9 +811,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
         const int ci = (wave + NW * t) * 64 + lane;
         const int slot = ci >> 2;
         const int lc = (ci & 3) ^ ((slot >> 2) & 3);
-        const int prow = slot / P, pcol = slot - prow * P;
-        const int v = v0 + prow;
-        const int n = v / HV, rr = v - n * HV - 1;
+        const int prow = div_magic(slot, a.mg_p), pcol = slot - prow * P;
+        const int vrel = v0 - n_first * HV + prow;                   // virtual row relative to the first image's (small: < PR + HV)
+        const int nrel = div_magic(vrel, a.mg_hv);
+        const int n = n_first + nrel, rr = vrel - nrel * HV - 1;
         const bool ok = (wave + NW * t) < a.n_pieces && prow < a.PR && (unsigned)rr < (unsigned)H && pcol >= 1 && pcol <= W && n < a.Nimg;
         pvoff[t] = ok ? 2u * (unsigned)((((n - n_first) * H + rr) * W + (pcol - 1)) * a.Cin + 8 * lc) : OOB;
     }
@@ -839,40 +847,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
         }
     };
 
-    // ---- A fragment addresses: pixel m of lane (i, lane & 31) -> slot s0 = (v(m) - 1 - v0) * P + c; tap (kh, kw) reads slot
-    // s0 + kh * P + kw; byte address = slot * 64 + 16 * (chunk ^ ((slot >> 2) & 3)), chunk = 2 g + half
+    // (fragment addresses a3 / cb and the accumulators are set up AFTER the prologue's loads have been issued, below: ~300-750
+    // instructions that now run under the first patch's round trip instead of in front of it)
     const int half = lane >> 5;
     unsigned a3[FM][3][2];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        int m = m0 + (wm * FM + i) * 32 + (lane & 31);
-        m = m < a.M ? m : a.M - 1;
-        const int n = m / HW, rem = m - n * HW, r = rem / W, c = rem - r * W;
-        const int s0 = (n * HV + r - v0) * P + c;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int t = s0 + kw;
-            const int e = half ^ ((t >> 2) & 3);
-            a3[i][kw][0] = (unsigned)(t * 64 + 16 * e);
-            a3[i][kw][1] = (unsigned)(t * 64 + 16 * (e ^ 2));
-        }
-    }
-    // B fragment addresses (inside stage 0): row lrow of the wave's j-th 32-channel block, chunk 2 g + half
     unsigned cb[2];
-    {
-        const int lrow = lane & 31, sw = (lrow >> 2) & 3;
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-            cb[g] = 2u * (unsigned)a.patch_bytes + (unsigned)(wn * FN * 32 * 64 + lrow * 64 + 16 * ((2 * g + half) ^ sw));
-    }
-
     f32x16 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // One step = one tap of one chunk on patch buffer `buf` and weight stage tap % 3: two k groups of FM * FN MFMAs.  Pinned
     // schedule (see the LDS-DMA kernel): group 1's fragments are read behind group 0's MFMAs; and because the patch of a chunk
@@ -961,6 +941,38 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
         issue_dummy();
         issue_w(2, 0, 2);
     }
+    // ---- A fragment addresses: pixel m of lane (i, lane & 31) -> slot s0 = (v(m) - 1 - v0) * P + c; tap (kh, kw) reads slot
+    // s0 + kh * P + kw; byte address = slot * 64 + 16 * (chunk ^ ((slot >> 2) & 3)), chunk = 2 g + half
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        int m = m0 + (wm * FM + i) * 32 + (lane & 31);
+        m = m < a.M ? m : a.M - 1;
+        const int rel = rem_first + (m - m0);                        // pixel offset from the first image's origin: < HW + BM
+        const int nr = div_magic(rel, a.mg_hw), rem = rel - nr * HW, r = div_magic(rem, a.mg_w), c = rem - r * W;
+        const int s0 = ((n_first + nr) * HV + r - v0) * P + c;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int t = s0 + kw;
+            const int e = half ^ ((t >> 2) & 3);
+            a3[i][kw][0] = (unsigned)(t * 64 + 16 * e);
+            a3[i][kw][1] = (unsigned)(t * 64 + 16 * (e ^ 2));
+        }
+    }
+    // B fragment addresses (inside stage 0): row lrow of the wave's j-th 32-channel block, chunk 2 g + half
+    {
+        const int lrow = lane & 31, sw = (lrow >> 2) & 3;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            cb[g] = 2u * (unsigned)a.patch_bytes + (unsigned)(wn * FN * 32 * 64 + lrow * 64 + 16 * ((2 * g + half) ^ sw));
+    }
+
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
     // step s: everything but the loads of the last NS - 3 + 1 steps has landed: with 3 stages the weights of step s (issued at
     // s - 2; step s - 1's loads may be in flight), with 4 stages the weights of step s + 1 (issued at s - 2) as well
 #ifndef RPG_PATCH_ABL
@@ -1078,6 +1090,10 @@ bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, c
     a.PR = rows + 2 * (imgs - 1) + 2;
     a.patch_bytes = (a.PR * a.P * 64 + 1023) / 1024 * 1024;
     a.n_pieces = a.patch_bytes / 1024;
+    auto magic = [](int d) { return (unsigned)((1ULL << 32) / (unsigned)d) + 1u; };
+    a.mg_p = magic(a.P); a.mg_hv = magic(H + 2); a.mg_hw = magic(HW); a.mg_w = magic(W);
+    // exactness of v_mul_hi(n, magic): n * d < 2^32 with n < patch slots (4096), patch rows + H + 2, H W + BM, H W respectively
+    if ((long)(HW + BM) * HW >= (1L << 32) || (long)(a.PR + H + 2 + 2) * (H + 2) >= (1L << 32)) return false;
     const int lds = 2 * a.patch_bytes + NS * BN * 64 + 1024;
     constexpr int slab = 8 * 32 * ((BN / WN / 32) * 32 + 4) * 4;
     if (a.n_pieces > 64 || lds > 160 * 1024 || lds < slab) return false;
