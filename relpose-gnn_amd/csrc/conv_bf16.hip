@@ -754,7 +754,7 @@ struct PatchArgs {
     // integer divisions per lane.
     unsigned mg_p, mg_hv, mg_hw, mg_w;
 };
-__device__ __forceinline__ int div_magic(int n, unsigned magic) { return (int)__umulhi((unsigned)n, magic); }
+__device__ __forceinline__ int div_magic(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }      // magic 0 = divisor 1
 
 __device__ __forceinline__ void dma_piece16_raw(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_byte_off, unsigned char* lds_base,
                                                 unsigned voffset, int soffset) {
@@ -1090,7 +1090,7 @@ bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, c
     a.PR = rows + 2 * (imgs - 1) + 2;
     a.patch_bytes = (a.PR * a.P * 64 + 1023) / 1024 * 1024;
     a.n_pieces = a.patch_bytes / 1024;
-    auto magic = [](int d) { return (unsigned)((1ULL << 32) / (unsigned)d) + 1u; };
+    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((1ULL << 32) / (unsigned)d) + 1u; };      // 0: divisor 1 (2^32 + 1 does not fit)
     a.mg_p = magic(a.P); a.mg_hv = magic(H + 2); a.mg_hw = magic(HW); a.mg_w = magic(W);
     // exactness of v_mul_hi(n, magic): n * d < 2^32 with n < patch slots (4096), patch rows + H + 2, H W + BM, H W respectively
     if ((long)(HW + BM) * HW >= (1L << 32) || (long)(a.PR + H + 2 + 2) * (H + 2) >= (1L << 32)) return false;

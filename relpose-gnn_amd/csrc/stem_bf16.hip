@@ -65,7 +65,8 @@ struct StemBArgs {
     int N, H, W, Hc, Wc, Hp, Wp;
     int TWp, tiles_x, tiles_y, RW, nfrag;
     int nxcd;              // 8: block b works on the images n = b % 8 (mod 8) -- see the tile loop; 1: tiles in plain order
-};
+    unsigned mg_rw, mg_tpi, mg_tx;      // floor(2^32 / d) + 1 for d = RW, tiles per image, tiles_x: the tile loop's divisions as one v_mul_hi
+};                                      // each (numerators: a pixel of the tile < 2^12, a tile index < 2^22; round 4)
 
 // byte offset of patch row (c, kh) relative to a pixel's first row
 __host__ __device__ constexpr int krow_off(int idx) { return ((idx / 7) * IR + idx % 7) * ROWB; }
@@ -101,10 +102,10 @@ __global__ __launch_bounds__(SB_NT) __attribute__((amdgpu_waves_per_eu(3, 3))) v
     const int tpi = a.tiles_y * a.tiles_x;
     const int xcd = blockIdx.x % a.nxcd, nslot = gridDim.x / a.nxcd;
     for (int lt = blockIdx.x / a.nxcd;; lt += nslot) {
-        const int li = lt / tpi, tr = lt - li * tpi;
+        const int li = a.mg_tpi ? (int)__umulhi((unsigned)lt, a.mg_tpi) : lt, tr = lt - li * tpi;       // (magic 0 = divisor 1)
         const int n = xcd + a.nxcd * li;
         if (n >= a.N) break;
-        const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+        const int ty = a.mg_tx ? (int)__umulhi((unsigned)tr, a.mg_tx) : tr, tx = tr - ty * a.tiles_x;
         const int P0 = ty * PH, Q0 = tx * a.TWp;
         const int cy0 = 2 * P0 - 1, cx0 = 2 * Q0 - 1;            // first convolution row / column of the tile
         const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;          // first input row / column of the patch
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(SB_NT) __attribute__((amdgpu_waves_per_eu(3, 3))) v
         for (int f = (wave - lt) & (NWV - 1); f < a.nfrag; f += NWV) {
             const int pl = f * 32 + (lane & 31);
             const int p = pl < npix ? pl : npix - 1;             // padding lanes of the last fragment: a valid pixel, not stored
-            const int oy = p / a.RW, ox = p - oy * a.RW;
+            const int oy = a.mg_rw ? (int)__umulhi((unsigned)p, a.mg_rw) : p, ox = p - oy * a.RW;
             const unsigned char* q = patch + (2 * oy * ROWB + 4 * ox);
             const unsigned char* qa = q + (h ? ROWB : 0);                 // half-wave 1 holds the next kernel row,
             const unsigned char* qb = q + (h ? (IR - 6) * ROWB : 0);      // the first row of the next plane (after kernel row 6),
@@ -265,9 +266,13 @@ int launch_stem_pool_bf16(const void* x_nchw, int x_is_bf16, const void* wpack, 
                                   SB_LDS_BYTES);
         attr[dev] = true;
     }
-    const int slot = timing_begin(RPG_TIMER_CONV, s);
     const int grid = (int)(total < (long)SB_WGS_PER_CU * num_cus() ? total : (long)SB_WGS_PER_CU * num_cus());
     a.nxcd = (grid % 8 == 0 && n >= 64) ? 8 : 1;
+    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((1ULL << 32) / (unsigned)d) + 1u; };      // 0: divisor 1 (2^32 + 1 does not fit)
+    a.mg_rw = magic(a.RW); a.mg_tpi = magic(a.tiles_y * a.tiles_x); a.mg_tx = magic(a.tiles_x);
+    // v_mul_hi exactness needs numerator * divisor < 2^32: the tile index lt < (images + grid) * tiles per image
+    if ((long)((long)n / a.nxcd + 1 + grid) * a.tiles_y * a.tiles_x * a.tiles_y * a.tiles_x >= (1L << 32)) return RPG_ERR_BAD_ARG;
+    const int slot = timing_begin(RPG_TIMER_CONV, s);
     if (x_is_bf16) hipLaunchKernelGGL(stem_pool_bf16_kernel<__bf16>, dim3(grid), dim3(SB_NT), SB_LDS_BYTES, s, a);
     else hipLaunchKernelGGL(stem_pool_bf16_kernel<float>, dim3(grid), dim3(SB_NT), SB_LDS_BYTES, s, a);
     // algorithmic: the 7x7x3 convolution on every output pixel; executed: fragments x 11 steps x 2 MFMAs x 32*32*16*2
