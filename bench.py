@@ -188,9 +188,9 @@ def bf16_roofline(kt):
     tf = c["work"] / (c["ms"] * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(tf, 2), "peak": BF16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / BF16_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
-            "kernel": "conv3x3_bf16_patch_kernel (3x3/s1 from 256 channels: input patch resident in LDS) / "
-                      "conv_bf16_dma_kernel (implicit GEMM, operands by LDS-DMA, counted vmcnt) / "
-                      "stem_pool_bf16_kernel (fused stem), all on v_mfma_f32_32x32x16_bf16",
+            "kernel": "conv3x3_bf16_patch_kernel (every 3x3/s1 convolution: input patch resident in LDS, branch-free epilogue, "
+                      "division-free tile set-up) / conv_bf16_dma_kernel (3x3/s2, 1x1/s2: implicit GEMM, operands by LDS-DMA, counted "
+                      "vmcnt) / stem_pool_bf16_kernel (fused stem), all on v_mfma_f32_32x32x16_bf16",
             "launches": c["launches"], "avg_launch_ms": round(c["ms"] / c["launches"], 4),
             "what": "achieved = ALGORITHMIC FLOP of all the encoder's convolution launches (2 * pixels * Cout * "
                     "kh * kw * Cin; the stem as 7x7x3) / their summed HIP-event durations in the one-stream pass"}
