@@ -336,6 +336,8 @@ int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
 #define RPG_TUNE_BF16_LEAN_EPI 23   /* bf16 convolutions (bf16 output, optional bf16 residual): 1 (default) the branch-free epilogue of round 4 (raw buffer
                                      accesses with out-of-range offsets instead of a branch per row, 32-bit offsets, residual as a template
                                      parameter: -7..-12 % on the convolution kernels) | 0: the general epilogue of rounds 1-3 */
+#define RPG_TUNE_BF16_LINEAR_DMA 24 /* bf16 GNN Linears on the edge rows (>= 192 tiles of 128 x 128): 0 the interleaved buffer-load kernel | 10 + i:
+                                     configuration i of the LDS-DMA convolution kernel (a Linear is a 1 x 1 convolution over an m-pixel image) */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -1023,6 +1023,7 @@ int g_bf16_lean_epi = 1;     // RPG_TUNE_BF16_LEAN_EPI: the branch-free epilogue
 int g_bf16_fused_stem = 1;   // RPG_TUNE_FUSED_STEM also selects the bf16 encoder's fused stem (stem_bf16.hip)
 int g_bf16_chunk = 0;        // RPG_TUNE_BF16_CHUNK: images per depth-first group of the bf16 encoder's identity-block runs (0 = off)
 int g_bf16_chunk_mb = 64;    // ... for activation tensors of at least this many MB
+int g_bf16_linear_dma = 0;   // RPG_TUNE_BF16_LINEAR_DMA: 0 = the interleaved buffer-load kernel | 10 + i: LDS-DMA configuration i
 int g_bf16_dma = 1;      // RPG_TUNE_BF16_DMA: 0 off | 1 by shape | 10 + i: configuration i of launch_dma_config wherever it is eligible
 int g_bf16_tile = -1;    // RPG_TUNE_BF16_TILE: -1 auto | 0: 64x64 | 1: 128x128 | 2: 256x64 | 3: 128x64 (interleaved kernel only)
 int g_bf16_fast = 1;     // RPG_TUNE_BF16_FAST: the interleaved buffer-load kernel where eligible
@@ -1225,6 +1226,7 @@ void bf16_set_dma(int v) { g_bf16_dma = v; }
 void bf16_set_patch(int v) { g_bf16_stages = v >= 10 ? 3 : 4; g_bf16_patch = v % 10; }
 void bf16_set_fused_stem(int on) { g_bf16_fused_stem = on; }
 void bf16_set_lean_epi(int on) { g_bf16_lean_epi = on; }
+void bf16_set_linear_dma(int v) { g_bf16_linear_dma = v; }
 void bf16_set_chunk(int images, int min_mb) { g_bf16_chunk = images; g_bf16_chunk_mb = min_mb; }
 #ifdef RPG_PROBE_WS64
 int bf16_set_ws64(int v) { g_bf16_ws64 = v; return RPG_OK; }
@@ -1286,7 +1288,11 @@ int launch_linear_bf16_ex(const void* a, int lda, const void* w, const float* bi
     const int slot = timing_begin(RPG_TIMER_LINEAR, s);
     const bool fast = g_bf16_fast && k % 64 == 0 && 258L * lda * 2 < (1L << 31) && (long)n_out * k * 2 < (1L << 31);
     const long t128 = (long)((m + 127) / 128) * ((n_out + 127) / 128);
-    if (fast) {
+    // RPG_TUNE_BF16_LINEAR_DMA = 10 + i: configuration i of the LDS-DMA kernel for the edge-row Linears (a 1 x 1 convolution over an
+    // m-pixel image; the general epilogue carries the gathers and the second output)
+    const bool dma_ok = 1026L * lda * 2 < (1L << 31) && (long)n_out * k * 2 < (1L << 31);
+    if (g_bf16_linear_dma >= 10 && dma_ok && t128 >= 192 && launch_dma_config(g_bf16_linear_dma - 10, ca, wp, m, n_out, k, ep, s)) {
+    } else if (fast) {
         if (t128 >= 192) launch_fast<128, 128, 2, 2>(ca, wp, m, n_out, k, ep, s);
         else launch_fast<64, 64, 2, 2>(ca, wp, m, n_out, k, ep, s);
     } else {

@@ -160,6 +160,44 @@ def test_linear_bf16(dev, m, k, n_out, gather):
     assert rel_err(out.cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 3, 7, 8])
+@pytest.mark.parametrize("m,k,n_out,gather", [(3584, 2048, 2048, 2), (1792, 4096, 2048, 0), (1801, 2048, 2056, 1)])
+def test_linear_bf16_on_dma_configs(dev, cfg, m, k, n_out, gather):
+    """RPG_TUNE_BF16_LINEAR_DMA = 10 + cfg: the edge-row Linears of the bf16 GNN on a configuration of the LDS-DMA kernel (a
+    1 x 1 convolution over an m-pixel image) -- plain / gathered / twice-gathered fp32 residual rows through the general
+    epilogue, ragged m and n_out; same reference and bar as test_linear_bf16."""
+    from relpose_gnn_amd import ops
+    a = _rand(m, k, seed=1)
+    w = _rand(n_out, k, seed=2, scale=k ** -0.5)
+    bias = _rand(n_out, seed=3)
+    ab = ops.f32_to_bf16(a.to(dev))
+    ref = F.linear(a.bfloat16().float(), w.bfloat16().float(), bias)
+    idx = res2 = idx2 = None
+    if gather == 0:
+        res = _rand(m, n_out, seed=4)
+        ref = ref + res
+    else:
+        g = torch.Generator().manual_seed(5)
+        res = _rand(50, 3 * n_out, seed=6)
+        idx = torch.randint(0, 50, (m,), generator=g)
+        ref = ref + res[idx, :n_out]
+        if gather == 2:
+            idx2 = torch.randint(0, 50, (m,), generator=g)
+            ref = ref + res[idx2, n_out:2 * n_out]
+    ref = F.relu(ref)
+    tdev = res.to(dev)
+    r2dev = tdev[:, n_out:] if gather == 2 else None
+    args = (ops, ab, w.bfloat16().to(dev), bias.to(dev), tdev, None if idx is None else idx.to(dev), r2dev,
+            None if idx2 is None else idx2.to(dev), 3 * n_out if gather else n_out, m, k, n_out)
+    base = _linear_bf16_raw(*args)
+    ops.set_tuning(ops.TUNE_BF16_LINEAR_DMA, 10 + cfg)
+    try:
+        out = _linear_bf16_raw(*args)
+    finally:
+        ops.set_tuning(ops.TUNE_BF16_LINEAR_DMA, 0)
+    assert rel_err(out.cpu(), ref) < 2e-5 and rel_err(base.cpu(), ref) < 2e-5
+
+
 @pytest.mark.parametrize("cfg", range(10))
 @pytest.mark.parametrize("n,h,w,cin,cout,k,stride,pad,res,relu,f32out", [
     (40, 56, 56, 64, 64, 3, 1, 1, True, True, False),     # layer-1 shape: 1 tap = 1 K step of 64, many M tiles, N = 64 < BN
