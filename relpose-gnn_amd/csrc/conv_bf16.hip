@@ -9,6 +9,12 @@
 // MFMA wants from it (k = 8*(lane>>5) + 0..7 of a 16-wide chunk), so no k permutation is involved here.
 // Looser parity bar than the f32 path: see tests (<= 3e-2 max-norm relative on the forward; stated there).
 #include "rpg_common.h"
+#ifdef RPG_PATCH_TRACE
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -748,13 +754,22 @@ struct PatchArgs {
     const __bf16* x;
     int H, W, Cin, Nimg, M, N, tiles_n;
     int P, PR, patch_bytes, n_pieces;      // slots per patch row, patch rows, bytes per patch buffer (multiple of 1 KB), 1-KB pieces
-    // floor(2^32 / d) + 1 for d = P, H + 2, H * W, W: the per-lane divisions of the tile set-up as one v_mul_hi each (exact for
-    // numerator * d < 2^32; every numerator here is a slot, a patch row or a pixel offset inside the tile: < 2^15).  Round 4: the
+    // floor(2^32 / d) + 1 for d = H + 2, H * W, W, P / 16: the divisions of the tile set-up as one mul_hi each (exact for
+    // numerator * d < 2^32; every numerator here is a piece index, a patch row or a pixel offset inside the tile: < 2^15).  Round 4: the
     // set-up was ~700 instructions before the first load of a tile went out, three quarters of them hipcc's expansion of 24
     // integer divisions per lane.
-    unsigned mg_p, mg_hv, mg_hw, mg_w;
+    unsigned mg_hv, mg_hw, mg_w, mg_p16;
+#ifdef RPG_PATCH_TRACE
+    unsigned long long* trace;             // probe builds (tools/probes/patch_trace.sh): 8 s_memtime stamps per workgroup
+#endif
 };
-__device__ __forceinline__ int div_magic(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }      // magic 0 = divisor 1
+#ifdef RPG_PATCH_TRACE
+#define RPG_PATCH_STAMP(K) do { if (a.trace && threadIdx.x == 0) { a.trace[(size_t)blockIdx.x * 16 + (K)] = __builtin_amdgcn_s_memtime(); if ((K) == 0 || (K) == 7) a.trace[(size_t)blockIdx.x * 16 + 8 + (K)] = wall_clock64(); } } while (0)
+#else
+#define RPG_PATCH_STAMP(K) do { } while (0)
+#endif
+// magic 0 = divisor 1 (2^32 + 1 does not fit): mul_hi gives 0 and the numerator is added back -- a select, not a branch
+__device__ __forceinline__ int div_magic(int n, unsigned magic) { return (int)(__umulhi((unsigned)n, magic) + (magic ? 0u : (unsigned)n)); }
 
 __device__ __forceinline__ void dma_piece16_raw(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_byte_off, unsigned char* lds_base,
                                                 unsigned voffset, int soffset) {
@@ -792,11 +807,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
     const int wm = wave / WN, wn = wave % WN;
     const int H = a.H, W = a.W, HW = a.H * a.W, P = a.P, HV = a.H + 2;
     const int NC = a.Cin / 32;
+    RPG_PATCH_STAMP(0);                                   // workgroup entry
 
     // ---- geometry of the tile: first virtual row of the patch, first image (wave-uniform: two real divisions)
     const int n_first = m0 / HW;
     const int rem_first = m0 - n_first * HW;                         // pixel of m0 inside its image
-    const int v0 = n_first * HV + rem_first / W;                     // = v(m0) - 1: the row above the tile's first pixel
+    const int v0 = n_first * HV + div_magic(rem_first, a.mg_w);     // = v(m0) - 1: the row above the tile's first pixel
     const int img = HW * a.Cin;
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x) + (size_t)n_first * img, 0,
                                                                           0x7fffffff, 0x00020000);
@@ -804,19 +820,31 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
     const unsigned dummy_off = 2u * (unsigned)a.patch_bytes + (unsigned)NS * BSTAGE;      // 1 KB nobody reads
 
     // ---- patch pieces of this wave: piece q = wave + 8 t (t = 0 .. 7) covers 16-byte chunks 64 q .. 64 q + 63 of the buffer;
-    // chunk ci = (slot ci >> 2, physical chunk ci & 3) <- logical chunk (ci & 3) ^ ((slot >> 2) & 3) of that pixel
+    // chunk ci = (slot ci >> 2, physical chunk ci & 3) <- logical chunk (ci & 3) ^ ((slot >> 2) & 3) of that pixel.
+    // A piece is 16 consecutive slots and P % 16 == 0, so a piece lies inside ONE patch row: its row, image and validity are
+    // wave-uniform (scalar unit: two s_mul_hi per piece), and a lane adds only its column -- five vector instructions per piece.
+    // (Phase trace of round 4: the per-lane form cost ~6 k cycles of a 27-k-cycle layer-1 tile before the first load went out:
+    // 220 vector instructions, 48 of them quarter-rate integer multiplies, 16 exec-mask branches.)
     unsigned pvoff[8];
+    {
+        const int s_l = lane >> 2;                                   // the lane's slot inside its piece
+        const int lc8 = 8 * ((lane & 3) ^ ((s_l >> 2) & 3));         // (slot >> 2) & 3 == (s_l >> 2) & 3: pieces start on multiples of 16 slots
+        const int p16 = P >> 4;                                      // pieces per patch row
+        const int vbase = v0 - n_first * HV;                         // = rem_first / W: patch row 0 relative to the first image's virtual rows
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int ci = (wave + NW * t) * 64 + lane;
-        const int slot = ci >> 2;
-        const int lc = (ci & 3) ^ ((slot >> 2) & 3);
-        const int prow = div_magic(slot, a.mg_p), pcol = slot - prow * P;
-        const int vrel = v0 - n_first * HV + prow;                   // virtual row relative to the first image's (small: < PR + HV)
-        const int nrel = div_magic(vrel, a.mg_hv);
-        const int n = n_first + nrel, rr = vrel - nrel * HV - 1;
-        const bool ok = (wave + NW * t) < a.n_pieces && prow < a.PR && (unsigned)rr < (unsigned)H && pcol >= 1 && pcol <= W && n < a.Nimg;
-        pvoff[t] = ok ? 2u * (unsigned)((((n - n_first) * H + rr) * W + (pcol - 1)) * a.Cin + 8 * lc) : OOB;
+        for (int t = 0; t < 8; ++t) {
+            const int q = wave + NW * t;                             // uniform
+            const int prow = div_magic(q, a.mg_p16);
+            const int col0 = (q - prow * p16) * 16;
+            const int vrel = vbase + prow;                           // < PR + HV
+            const int nrel = div_magic(vrel, a.mg_hv);
+            const int rr = vrel - nrel * HV - 1;
+            const bool rowok = q < a.n_pieces && prow < a.PR && (unsigned)rr < (unsigned)H && n_first + nrel < a.Nimg;
+            const int rowbase = ((nrel * H + rr) * W - 1) * a.Cin;   // element offset of column "pcol = 0" (the left halo slot) of that image row
+            const int pcol = col0 + s_l;
+            const unsigned off = 2u * (unsigned)(rowbase + __mul24(pcol, a.Cin) + lc8);
+            pvoff[t] = (rowok && (unsigned)(pcol - 1) < (unsigned)W) ? off : OOB;
+        }
     }
     // weight pieces: piece j covers rows 16 (wave + 8 j) .. + 15 of the stage; lane: row l >> 2, physical chunk l & 3
     unsigned woff[JB];
@@ -889,6 +917,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
         constexpr int G = FM * FN;
         constexpr int AHEAD = NS - 1;                          // weights are issued this many steps ahead
         __builtin_amdgcn_sched_barrier(0);
+#ifdef RPG_PATCH_TRACE
+        if (first && tap == 0) RPG_PATCH_STAMP(3);        // the first step's barrier has passed: patch chunk 0 + first weights landed
+        if (chunk == 1 && tap == 0) RPG_PATCH_STAMP(4);   // chunk 0 done (nine steps)
+#endif
         if (tap == 0) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) read_a(0, 0, i, tap);
@@ -941,6 +973,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
         issue_dummy();
         issue_w(2, 0, 2);
     }
+    RPG_PATCH_STAMP(1);                                   // set-up of the load addresses done, prologue loads issued
     // ---- A fragment addresses: pixel m of lane (i, lane & 31) -> slot s0 = (v(m) - 1 - v0) * P + c; tap (kh, kw) reads slot
     // s0 + kh * P + kw; byte address = slot * 64 + 16 * (chunk ^ ((slot >> 2) & 3)), chunk = 2 g + half
 #pragma unroll
@@ -973,6 +1006,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    RPG_PATCH_STAMP(2);                                   // fragment addresses / accumulators set up: the K loop starts waiting
     // step s: everything but the loads of the last NS - 3 + 1 steps has landed: with 3 stages the weights of step s (issued at
     // s - 2; step s - 1's loads may be in flight), with 4 stages the weights of step s + 1 (issued at s - 2) as well
 #ifndef RPG_PATCH_ABL
@@ -1007,6 +1041,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    RPG_PATCH_STAMP(5);                                   // K loop done
     if (RPG_PATCH_ABL & 1) {               // keep the accumulators alive, store (almost) nothing
         float sacc = 0.f;
 #pragma unroll
@@ -1017,6 +1052,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
         return;
     }
     bf16_tile_epilogue_any<FM, FN, 160 * 1024, NW>(acc, lds_raw, ep, m0, n0, a.M, a.N, wm, wn, lane, wave);
+#ifdef RPG_PATCH_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    RPG_PATCH_STAMP(6);                                   // epilogue instructions issued (the stores may still be in flight)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RPG_PATCH_STAMP(7);                                   // ... and acknowledged
+#endif
 }
 
 int g_bf16_lean_epi = 1;     // RPG_TUNE_BF16_LEAN_EPI: the branch-free epilogue for plain convolutions (0: the general one, rounds 1-3)
@@ -1092,7 +1133,7 @@ bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, c
     a.patch_bytes = (a.PR * a.P * 64 + 1023) / 1024 * 1024;
     a.n_pieces = a.patch_bytes / 1024;
     auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((1ULL << 32) / (unsigned)d) + 1u; };      // 0: divisor 1 (2^32 + 1 does not fit)
-    a.mg_p = magic(a.P); a.mg_hv = magic(H + 2); a.mg_hw = magic(HW); a.mg_w = magic(W);
+    a.mg_hv = magic(H + 2); a.mg_hw = magic(HW); a.mg_w = magic(W); a.mg_p16 = magic(a.P / 16);
     // exactness of v_mul_hi(n, magic): n * d < 2^32 with n < patch slots (4096), patch rows + H + 2, H W + BM, H W respectively
     if ((long)(HW + BM) * HW >= (1L << 32) || (long)(a.PR + H + 2 + 2) * (H + 2) >= (1L << 32)) return false;
     const int lds = 2 * a.patch_bytes + NS * BN * 64 + 1024;
@@ -1108,7 +1149,50 @@ bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, c
         once[dev] = true;
     }
     const int tm = (M + BM - 1) / BM;
+#ifdef RPG_PATCH_TRACE
+    // probe build: with RPG_PATCH_TRACE=1 in the environment every launch is synchronous and prints the median phase lengths of its
+    // workgroups (s_memtime ticks) to stderr
+    static const bool tracing = getenv("RPG_PATCH_TRACE") != nullptr;
+    const int nwg_trace = tm * a.tiles_n;
+    static unsigned long long* tbuf = nullptr;
+    static int tcap = 0;
+    if (tracing) {
+        if (nwg_trace > tcap) {
+            if (tbuf) (void)hipFree(tbuf);
+            (void)hipMalloc(reinterpret_cast<void**>(&tbuf), (size_t)nwg_trace * 128);
+            tcap = nwg_trace;
+        }
+        (void)hipMemsetAsync(tbuf, 0, (size_t)nwg_trace * 128, s);
+        a.trace = tbuf;
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3(tm * a.tiles_n), dim3(512), lds, s, a, w, ep);
+#ifdef RPG_PATCH_TRACE
+    if (tracing) {
+        std::vector<unsigned long long> h((size_t)nwg_trace * 16);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), tbuf, h.size() * 8, hipMemcpyDeviceToHost);
+        auto median = [&](int k0, int k1) {
+            std::vector<long long> d;
+            for (int g = 0; g < nwg_trace; ++g) d.push_back((long long)(h[(size_t)g * 16 + k1] - h[(size_t)g * 16 + k0]));
+            std::sort(d.begin(), d.end());
+            return d[d.size() / 2];
+        };
+        // wall_clock64 (100 MHz) at entry / exit: the launch's span, the sum of the workgroup lives, and the s_memtime rate
+        unsigned long long lo = ~0ULL, hi = 0;
+        double life_wall = 0, life_mem = 0;
+        for (int g = 0; g < nwg_trace; ++g) {
+            lo = std::min(lo, h[(size_t)g * 16 + 8]); hi = std::max(hi, h[(size_t)g * 16 + 15]);
+            life_wall += (double)(h[(size_t)g * 16 + 15] - h[(size_t)g * 16 + 8]);
+            life_mem += (double)(h[(size_t)g * 16 + 7] - h[(size_t)g * 16]);
+        }
+        fprintf(stderr, "patch_trace <%d,%d,NS%d> wgs %d M %d N %d Cin %d | set-up+issue %lld  frag set-up %lld  wait first data %lld  chunk0 %lld  "
+                "rest of K loop %lld  epilogue issue %lld  store ack %lld | life %lld ticks = %.2f us (s_memtime %.0f MHz) | launch span %.1f us, "
+                "sum of lives / 256 CUs %.1f us\n", BM, BN, NS, nwg_trace, M, N, c.Cin,
+                median(0, 1), median(1, 2), median(2, 3), median(3, 4), median(4, 5), median(5, 6), median(6, 7), median(0, 7),
+                median(8, 15) * 0.01, life_mem / life_wall * 100.0, (double)(hi - lo) * 0.01, life_wall * 0.01 / 256.0);
+    }
+#endif
     return true;
 }
 
