@@ -338,6 +338,11 @@ int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
                                      parameter: -7..-12 % on the convolution kernels) | 0: the general epilogue of rounds 1-3 */
 #define RPG_TUNE_BF16_LINEAR_DMA 24 /* bf16 GNN Linears on the edge rows (>= 192 tiles of 128 x 128): 0 the interleaved buffer-load kernel | 10 + i:
                                      configuration i of the LDS-DMA convolution kernel (a Linear is a 1 x 1 convolution over an m-pixel image) */
+#define RPG_TUNE_BF16_PERSIST 25    /* bf16 3x3 / stride-1 convolutions with <= 64 output channels (layer 1) on more than one round of tiles: 1 = the persistent
+                                     form of the patch kernel (one workgroup per CU walks its tiles; the next tile's first patch chunk and weights are
+                                     loaded during the current tile's last chunk and epilogue).  The kernel is 10 % (in the model) to 15 % (stand-alone)
+                                     faster; the default two-stream step is 2 % SLOWER with it (resident workgroups leave the other stream no gaps), so
+                                     the default is 0 = one workgroup per tile.  For single-stream use */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -752,7 +752,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
 // Requirements: Cin % 64 == 0 (an even number of chunks), patch <= 64 KB per buffer, 32-bit offsets (launcher).
 struct PatchArgs {
     const __bf16* x;
-    int H, W, Cin, Nimg, M, N, tiles_n;
+    int H, W, Cin, Nimg, M, N, tiles_n, n_tiles;
     int P, PR, patch_bytes, n_pieces;      // slots per patch row, patch rows, bytes per patch buffer (multiple of 1 KB), 1-KB pieces
     // floor(2^32 / d) + 1 for d = H + 2, H * W, W, P / 16: the divisions of the tile set-up as one mul_hi each (exact for
     // numerator * d < 2^32; every numerator here is a piece index, a patch row or a pixel offset inside the tile: < 2^15).  Round 4: the
@@ -776,7 +776,12 @@ __device__ __forceinline__ void dma_piece16_raw(__amdgpu_buffer_rsrc_t rsrc, uns
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(lds_base + lds_byte_off), 16, voffset, soffset, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
+// PS = persistent (round 4): one workgroup per CU walks tiles bid, bid + grid, ...; during a tile's LAST chunk the patch slot of the
+// steps loads the NEXT tile's first chunk into patch buffer 0 and the weight slot wraps to the next tile's first steps, and the epilogue
+// slabs live beside patch buffer 1 (LDS layout: buffer 0 | weight stages | dummy | buffer 1 / slabs) -- so a tile's ~10 k cycles of
+// set-up + first-load latency (phase trace: 36 % of a layer-1 tile's life, plus ~2 us of workgroup turnaround) run under the previous
+// tile's last chunk and epilogue.  Requires tiles_n == 1 (the weight offsets are those of the previous tile).
+template <int BM, int BN, int WM, int WN, int NS, bool PS = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchArgs a, const __bf16* __restrict__ Wt, EpiB ep) {
     // NS = weight stages.  3: the weights of step s + 2 are issued at step s and may be read from step s + 2's barrier on.
     // 4: issued THREE steps ahead, waited for one step early -- at step s's barrier the weights of step s + 1 are already
@@ -799,9 +804,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3, q8 = nwg >> 3, r8 = nwg & 7;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-    const int m0 = (tile / a.tiles_n) * BM;
-    const int n0 = (tile % a.tiles_n) * BN;
+    int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    int m0 = PS ? tile * BM : (tile / a.tiles_n) * BM;
+    const int n0 = PS ? 0 : (tile % a.tiles_n) * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -809,28 +814,31 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
     const int NC = a.Cin / 32;
     RPG_PATCH_STAMP(0);                                   // workgroup entry
 
-    // ---- geometry of the tile: first virtual row of the patch, first image (wave-uniform: two real divisions)
-    const int n_first = m0 / HW;
-    const int rem_first = m0 - n_first * HW;                         // pixel of m0 inside its image
-    const int v0 = n_first * HV + div_magic(rem_first, a.mg_w);     // = v(m0) - 1: the row above the tile's first pixel
+    // ---- LDS layout (byte offsets): patch buffer 0 at 0; one-shot form: buffer 1 | weight stages | dummy KB; persistent form: weight
+    // stages | dummy KB | buffer 1, which doubles as the epilogue slabs while buffer 0 and the stages take the next tile's first loads
+    const unsigned off_b1 = PS ? (unsigned)a.patch_bytes + (unsigned)NS * BSTAGE + 1024u : (unsigned)a.patch_bytes;
+    const unsigned off_st = PS ? (unsigned)a.patch_bytes : 2u * (unsigned)a.patch_bytes;
+    const unsigned dummy_off = off_st + (unsigned)NS * BSTAGE;       // 1 KB nobody reads
     const int img = HW * a.Cin;
-    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x) + (size_t)n_first * img, 0,
-                                                                          0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wt), 0, 0x7fffffff, 0x00020000);
-    const unsigned dummy_off = 2u * (unsigned)a.patch_bytes + (unsigned)NS * BSTAGE;      // 1 KB nobody reads
 
-    // ---- patch pieces of this wave: piece q = wave + 8 t (t = 0 .. 7) covers 16-byte chunks 64 q .. 64 q + 63 of the buffer;
+    // ---- geometry of a tile: first image, first virtual row of the patch (wave-uniform: one real division), and the patch pieces of
+    // this wave: piece q = wave + 8 t (t = 0 .. 7) covers 16-byte chunks 64 q .. 64 q + 63 of the buffer;
     // chunk ci = (slot ci >> 2, physical chunk ci & 3) <- logical chunk (ci & 3) ^ ((slot >> 2) & 3) of that pixel.
     // A piece is 16 consecutive slots and P % 16 == 0, so a piece lies inside ONE patch row: its row, image and validity are
     // wave-uniform (scalar unit: two s_mul_hi per piece), and a lane adds only its column -- five vector instructions per piece.
     // (Phase trace of round 4: the per-lane form cost ~6 k cycles of a 27-k-cycle layer-1 tile before the first load went out:
     // 220 vector instructions, 48 of them quarter-rate integer multiplies, 16 exec-mask branches.)
+    int n_first, rem_first, v0;
     unsigned pvoff[8];
-    {
+    auto geometry = [&](int m0_, bool valid, int& nf, int& rf, int& v0_) {
+        nf = m0_ / HW;
+        rf = m0_ - nf * HW;                                          // pixel of m0 inside its image
+        v0_ = nf * HV + div_magic(rf, a.mg_w);                       // = v(m0) - 1: the row above the tile's first pixel
         const int s_l = lane >> 2;                                   // the lane's slot inside its piece
         const int lc8 = 8 * ((lane & 3) ^ ((s_l >> 2) & 3));         // (slot >> 2) & 3 == (s_l >> 2) & 3: pieces start on multiples of 16 slots
         const int p16 = P >> 4;                                      // pieces per patch row
-        const int vbase = v0 - n_first * HV;                         // = rem_first / W: patch row 0 relative to the first image's virtual rows
+        const int vbase = v0_ - nf * HV;                             // patch row 0 relative to the first image's virtual rows
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int q = wave + NW * t;                             // uniform
@@ -839,45 +847,50 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
             const int vrel = vbase + prow;                           // < PR + HV
             const int nrel = div_magic(vrel, a.mg_hv);
             const int rr = vrel - nrel * HV - 1;
-            const bool rowok = q < a.n_pieces && prow < a.PR && (unsigned)rr < (unsigned)H && n_first + nrel < a.Nimg;
+            const bool rowok = valid && q < a.n_pieces && prow < a.PR && (unsigned)rr < (unsigned)H && nf + nrel < a.Nimg;
             const int rowbase = ((nrel * H + rr) * W - 1) * a.Cin;   // element offset of column "pcol = 0" (the left halo slot) of that image row
             const int pcol = col0 + s_l;
             const unsigned off = 2u * (unsigned)(rowbase + __mul24(pcol, a.Cin) + lc8);
             pvoff[t] = (rowok && (unsigned)(pcol - 1) < (unsigned)W) ? off : OOB;
         }
-    }
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x) + (size_t)nf * img, 0, 0x7fffffff, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t rs_p = geometry(m0, true, n_first, rem_first, v0);       // the patch loads' resource: based at the tile's first image
+    // persistent form, while a tile's last chunk runs: the patch slot loads the NEXT tile's chunk 0 (pvoff / rs_p already the next
+    // tile's; c_off cancels the chunk index in the scalar offset) and the weight slot wraps to its first steps
+    int c_off = 0;
+    bool wrap_live = false;
     // weight pieces: piece j covers rows 16 (wave + 8 j) .. + 15 of the stage; lane: row l >> 2, physical chunk l & 3
     unsigned woff[JB];
-    {
-        const int r_in = lane >> 2;
-        const int lc = (lane & 3) ^ ((r_in >> 2) & 3);
+    auto set_woff = [&](int l) {
+        const int r_in = l >> 2;
+        const int lc = (l & 3) ^ ((r_in >> 2) & 3);
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
             const int n = n0 + (wave + NW * j) * 16 + r_in;
             woff[j] = n < a.N ? 2u * (unsigned)(n * 9 * a.Cin + 8 * lc) : OOB;
         }
-    }
+    };
+    set_woff(lane);
     // patch piece t of chunk `chunk` -> patch buffer `buf` (dummy target when this wave has no t-th piece)
     auto issue_patch = [&](int t, int buf, int chunk) {
         const bool real = (wave + NW * t) < a.n_pieces;
-        const unsigned dst = real ? (unsigned)(buf * a.patch_bytes + (wave + NW * t) * 1024) : dummy_off;
-        dma_piece16_raw(rsa, dst, lds_raw, chunk < NC ? pvoff[t] : OOB, chunk * 64);
+        const unsigned dst = real ? (buf ? off_b1 : 0u) + (unsigned)((wave + NW * t) * 1024) : dummy_off;
+        dma_piece16_raw(rs_p, dst, lds_raw, (chunk < NC || (PS && wrap_live)) ? pvoff[t] : OOB, chunk * 64 + (PS ? c_off : 0));
     };
-    auto issue_dummy = [&]() { dma_piece16_raw(rsa, dummy_off, lds_raw, OOB, 0); };
+    auto issue_dummy = [&]() { dma_piece16_raw(rsw, dummy_off, lds_raw, OOB, 0); };
     // the weights of (chunk, tap) -> stage `stage`
     auto issue_w = [&](int stage, int chunk, int tap) {
-        const bool live = chunk < NC;
+        const bool live = chunk < NC || (PS && wrap_live);
+        const int cw = (PS && chunk >= NC) ? 0 : chunk;                // past the tile's end: the next tile's first chunk
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
             if (NBP < NW && wave >= NBP) issue_dummy();
-            else dma_piece16_raw(rsw, 2u * (unsigned)a.patch_bytes + (unsigned)(stage * BSTAGE + (wave + NW * j) * 1024), lds_raw,
-                                 live ? woff[j] : OOB, (tap * a.Cin + chunk * 32) * 2);
+            else dma_piece16_raw(rsw, off_st + (unsigned)(stage * BSTAGE + (wave + NW * j) * 1024), lds_raw,
+                                 live ? woff[j] : OOB, (tap * a.Cin + cw * 32) * 2);
         }
     };
 
-    // (fragment addresses a3 / cb and the accumulators are set up AFTER the prologue's loads have been issued, below: ~300-750
-    // instructions that now run under the first patch's round trip instead of in front of it)
-    const int half = lane >> 5;
     unsigned a3[FM][3][2];
     unsigned cb[2];
     f32x16 acc[FM][FN];
@@ -897,7 +910,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
         fr[set][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds_raw + (a3[i][tap % 3][g] + aoff)));
     };
     auto flip_patch = [&](int buf) {                           // after a chunk on buffer `buf`: the next chunk reads the other one
-        const unsigned d = buf == 0 ? (unsigned)a.patch_bytes : 0u - (unsigned)a.patch_bytes;
+        const unsigned d = buf == 0 ? off_b1 : 0u - off_b1;
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -974,39 +987,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
         issue_w(2, 0, 2);
     }
     RPG_PATCH_STAMP(1);                                   // set-up of the load addresses done, prologue loads issued
-    // ---- A fragment addresses: pixel m of lane (i, lane & 31) -> slot s0 = (v(m) - 1 - v0) * P + c; tap (kh, kw) reads slot
-    // s0 + kh * P + kw; byte address = slot * 64 + 16 * (chunk ^ ((slot >> 2) & 3)), chunk = 2 g + half
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        int m = m0 + (wm * FM + i) * 32 + (lane & 31);
-        m = m < a.M ? m : a.M - 1;
-        const int rel = rem_first + (m - m0);                        // pixel offset from the first image's origin: < HW + BM
-        const int nr = div_magic(rel, a.mg_hw), rem = rel - nr * HW, r = div_magic(rem, a.mg_w), c = rem - r * W;
-        const int s0 = ((n_first + nr) * HV + r - v0) * P + c;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int t = s0 + kw;
-            const int e = half ^ ((t >> 2) & 3);
-            a3[i][kw][0] = (unsigned)(t * 64 + 16 * e);
-            a3[i][kw][1] = (unsigned)(t * 64 + 16 * (e ^ 2));
-        }
-    }
-    // B fragment addresses (inside stage 0): row lrow of the wave's j-th 32-channel block, chunk 2 g + half
-    {
-        const int lrow = lane & 31, sw = (lrow >> 2) & 3;
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-            cb[g] = 2u * (unsigned)a.patch_bytes + (unsigned)(wn * FN * 32 * 64 + lrow * 64 + 16 * ((2 * g + half) ^ sw));
-    }
 
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    RPG_PATCH_STAMP(2);                                   // fragment addresses / accumulators set up: the K loop starts waiting
     // step s: everything but the loads of the last NS - 3 + 1 steps has landed: with 3 stages the weights of step s (issued at
     // s - 2; step s - 1's loads may be in flight), with 4 stages the weights of step s + 1 (issued at s - 2) as well
 #ifndef RPG_PATCH_ABL
@@ -1032,26 +1013,104 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
         RPG_PATCH_STEP(BUF, 8, CHUNK, sb, false, l8);                                                                    \
         flip_patch(BUF);                                                                                                 \
     } while (0)
-    for (int cc = 0; cc < NC; cc += 2) {
-        RPG_PATCH_CHUNK(0, cc, (9 * cc) & 3);
-        RPG_PATCH_CHUNK(1, cc + 1, (9 * cc + 9) & 3);
-    }
-#undef RPG_PATCH_CHUNK
-#undef RPG_PATCH_STEP
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    RPG_PATCH_STAMP(5);                                   // K loop done
-    if (RPG_PATCH_ABL & 1) {               // keep the accumulators alive, store (almost) nothing
-        float sacc = 0.f;
+
+    int sb0 = 0;                                          // steps done before this tile, modulo 4 (stage rotation of the four-stage form)
+    bool first_tile = true;
+    for (;;) {
+        // persistent form: every lane-derived address is rebuilt per tile from an opaque copy of the lane index -- kept live across the
+        // epilogue (which needs the whole register file beside the accumulators) they were spilled to scratch (130 VGPRs on the 512 x 128 tile)
+        int lt = lane;
+        if (PS) {
+            asm volatile("" : "+v"(lt));
+            if (!first_tile) set_woff(lt);
+        }
+        const int half = lt >> 5;
+        // B fragment addresses (inside stage 0): row lrow of the wave's j-th 32-channel block, chunk 2 g + half
+        {
+            const int lrow = lt & 31, sw = (lrow >> 2) & 3;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                cb[g] = off_st + (unsigned)(wn * FN * 32 * 64 + lrow * 64 + 16 * ((2 * g + half) ^ sw));
+        }
+        // ---- A fragment addresses: pixel m of lane (i, lane & 31) -> slot s0 = (v(m) - 1 - v0) * P + c; tap (kh, kw) reads slot
+        // s0 + kh * P + kw; byte address = slot * 64 + 16 * (chunk ^ ((slot >> 2) & 3)), chunk = 2 g + half.  (Set up AFTER the tile's
+        // first loads have been issued: these instructions run under the first patch's round trip instead of in front of it.)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            int m = m0 + (wm * FM + i) * 32 + (lt & 31);
+            m = m < a.M ? m : a.M - 1;
+            const int rel = rem_first + (m - m0);                    // pixel offset from the first image's origin: < HW + BM
+            const int nr = div_magic(rel, a.mg_hw), rem = rel - nr * HW, r = div_magic(rem, a.mg_w), c = rem - r * W;
+            const int s0 = ((n_first + nr) * HV + r - v0) * P + c;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int t = s0 + kw;
+                const int e = half ^ ((t >> 2) & 3);
+                a3[i][kw][0] = (unsigned)(t * 64 + 16 * e);
+                a3[i][kw][1] = (unsigned)(t * 64 + 16 * (e ^ 2));
+            }
+        }
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) sacc += acc[i][j][0] + acc[i][j][9];
-        if (sacc == 123.456f) reinterpret_cast<__bf16*>(ep.out)[tid] = (__bf16)sacc;
-        return;
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        RPG_PATCH_STAMP(2);                               // fragment addresses / accumulators set up: the K loop starts waiting
+
+        // persistent form: the tile after this one (its geometry is computed in front of the last chunk, below)
+        const int tile_n = tile + nwg, m0_n = tile_n * BM;
+        const bool has_next = PS && tile_n < a.n_tiles;
+        int nf_n = 0, rf_n = 0, v0_n = 0;
+        if (PS && !first_tile) {
+            // the previous tile's stores are acknowledged and this tile's first chunk + first weights (issued during its last chunk)
+            // have landed: the counted waits of the steps start from zero again
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        for (int cc = 0; cc < NC; cc += 2) {
+            RPG_PATCH_CHUNK(0, cc, (sb0 + 9 * cc) & 3);
+            if (PS && cc + 2 >= NC) {
+                // in front of the tile's LAST chunk (on buffer 1; NC is even): from here on the loads are the next tile's.  Without a
+                // next tile every offset is out of range (zero pieces, same instruction count).
+                rs_p = geometry(m0_n, has_next, nf_n, rf_n, v0_n);
+                c_off = -NC * 64;
+                wrap_live = has_next;
+            }
+            RPG_PATCH_CHUNK(1, cc + 1, (sb0 + 9 * cc + 9) & 3);
+        }
+        if (PS) {
+            // every wave has finished reading buffer 1 and the stages of this tile; buffer 0 / the stages are being filled for the next
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        RPG_PATCH_STAMP(5);                               // K loop done
+        if (RPG_PATCH_ABL & 1) {           // keep the accumulators alive, store (almost) nothing
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) sacc += acc[i][j][0] + acc[i][j][9];
+            if (sacc == 123.456f) reinterpret_cast<__bf16*>(ep.out)[tid] = (__bf16)sacc;
+        } else {
+            if constexpr (PS) {       // plain convolutions only (launcher): the lean epilogue, slabs beside patch buffer 1
+                if (ep.residual) bf16_tile_epilogue_lean_body<FM, FN, NW, true>(acc, lds_raw + off_b1, ep, m0, n0, a.M, a.N, wm, wn, lane, wave);
+                else bf16_tile_epilogue_lean_body<FM, FN, NW, false>(acc, lds_raw + off_b1, ep, m0, n0, a.M, a.N, wm, wn, lane, wave);
+            } else {
+                bf16_tile_epilogue_any<FM, FN, 160 * 1024, NW>(acc, lds_raw, ep, m0, n0, a.M, a.N, wm, wn, lane, wave);
+            }
+        }
+        if (!PS || !has_next) break;
+        tile = tile_n; m0 = m0_n; n_first = nf_n; rem_first = rf_n; v0 = v0_n;
+        c_off = 0;
+        wrap_live = false;
+        sb0 = (sb0 + 9 * NC) & 3;
+        first_tile = false;
     }
-    bf16_tile_epilogue_any<FM, FN, 160 * 1024, NW>(acc, lds_raw, ep, m0, n0, a.M, a.N, wm, wn, lane, wave);
+#undef RPG_PATCH_CHUNK
+#undef RPG_PATCH_STEP
 #ifdef RPG_PATCH_TRACE
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     RPG_PATCH_STAMP(6);                                   // epilogue instructions issued (the stores may still be in flight)
@@ -1117,10 +1176,15 @@ void launch_dma(const ConvArgsB& a, const __bf16* w, int M, int N, int K, const 
 }
 
 int g_bf16_stages = 4;   // weight stages of the patch kernel (experiments: 3 = never the prefetching form); RPG_TUNE_BF16_PATCH + 10
+// RPG_TUNE_BF16_PERSIST: the persistent form of the patch kernel (cross-tile prefetch) on the 64-channel layer.  OFF by default: the kernel
+// itself is 10 % (in the model) to 15 % (stand-alone) faster, but 256 resident workgroups hold every CU for the whole launch, and the
+// default two-stream schedule lives on the other stream's workgroups slipping into this launch's gaps: configs[2] 13.53-13.60 k graphs/s
+// without it, 13.26-13.39 k with it (same box, alternating runs; one-stream kernel sums equal).
+int g_bf16_persist = 0;
 int g_bf16_patch = 1;    // RPG_TUNE_BF16_PATCH: the patch kernel for 3x3 / stride-1 convolutions: 0 off | 1 by shape | 2 wherever eligible
 
 // The patch kernel, if the shape is eligible (3x3, stride 1, pad 1, Cin % 64 == 0, patch <= 64 pieces, 32-bit offsets, LDS fits)
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, bool PS = false>
 bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, const EpiB& ep, hipStream_t s) {
     if (c.KH != 3 || c.KW != 3 || c.stride != 1 || c.pad != 1 || (c.Cin & 63) || c.img_elems) return false;
     const int H = c.H, W = c.W, HW = H * W;
@@ -1136,11 +1200,21 @@ bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, c
     a.mg_hv = magic(H + 2); a.mg_hw = magic(HW); a.mg_w = magic(W); a.mg_p16 = magic(a.P / 16);
     // exactness of v_mul_hi(n, magic): n * d < 2^32 with n < patch slots (4096), patch rows + H + 2, H W + BM, H W respectively
     if ((long)(HW + BM) * HW >= (1L << 32) || (long)(a.PR + H + 2 + 2) * (H + 2) >= (1L << 32)) return false;
-    const int lds = 2 * a.patch_bytes + NS * BN * 64 + 1024;
     constexpr int slab = 8 * 32 * ((BN / WN / 32) * 32 + 4) * 4;
+    const int tm = (M + BM - 1) / BM;
+    a.n_tiles = tm * a.tiles_n;
+    int lds = 2 * a.patch_bytes + NS * BN * 64 + 1024;
+    int grid = a.n_tiles;
+    if (PS) {
+        // persistent form: one workgroup per CU, more than one round of tiles, one channel tile (the weight offsets carry over), the
+        // epilogue slabs beside patch buffer 1 (kernel comment)
+        grid = rpg::num_cus();
+        if (!ep.lean || a.tiles_n != 1 || a.n_tiles <= grid || (long)a.n_tiles * BM >= (1L << 31)) return false;
+        lds = a.patch_bytes + NS * BN * 64 + 1024 + (a.patch_bytes > slab ? a.patch_bytes : slab);
+    }
     if (a.n_pieces > 64 || lds > 160 * 1024 || lds < slab) return false;
     if ((long)(imgs + 1) * HW * c.Cin * 2 >= (1L << 31) || (long)N * 9 * c.Cin * 2 >= (1L << 31)) return false;
-    auto kern = conv3x3_bf16_patch_kernel<BM, BN, WM, WN, NS>;
+    auto kern = conv3x3_bf16_patch_kernel<BM, BN, WM, WN, NS, PS>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     static bool once[64] = {};
@@ -1148,12 +1222,11 @@ bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, c
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         once[dev] = true;
     }
-    const int tm = (M + BM - 1) / BM;
 #ifdef RPG_PATCH_TRACE
     // probe build: with RPG_PATCH_TRACE=1 in the environment every launch is synchronous and prints the median phase lengths of its
     // workgroups (s_memtime ticks) to stderr
     static const bool tracing = getenv("RPG_PATCH_TRACE") != nullptr;
-    const int nwg_trace = tm * a.tiles_n;
+    const int nwg_trace = grid;
     static unsigned long long* tbuf = nullptr;
     static int tcap = 0;
     if (tracing) {
@@ -1166,7 +1239,7 @@ bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, c
         a.trace = tbuf;
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3(tm * a.tiles_n), dim3(512), lds, s, a, w, ep);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a, w, ep);
 #ifdef RPG_PATCH_TRACE
     if (tracing) {
         std::vector<unsigned long long> h((size_t)nwg_trace * 16);
@@ -1186,9 +1259,9 @@ bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, c
             life_wall += (double)(h[(size_t)g * 16 + 15] - h[(size_t)g * 16 + 8]);
             life_mem += (double)(h[(size_t)g * 16 + 7] - h[(size_t)g * 16]);
         }
-        fprintf(stderr, "patch_trace <%d,%d,NS%d> wgs %d M %d N %d Cin %d | set-up+issue %lld  frag set-up %lld  wait first data %lld  chunk0 %lld  "
+        fprintf(stderr, "patch_trace <%d,%d,NS%d%s> wgs %d M %d N %d Cin %d | set-up+issue %lld  frag set-up %lld  wait first data %lld  chunk0 %lld  "
                 "rest of K loop %lld  epilogue issue %lld  store ack %lld | life %lld ticks = %.2f us (s_memtime %.0f MHz) | launch span %.1f us, "
-                "sum of lives / 256 CUs %.1f us\n", BM, BN, NS, nwg_trace, M, N, c.Cin,
+                "sum of lives / 256 CUs %.1f us\n", BM, BN, NS, PS ? ",persistent" : "", nwg_trace, M, N, c.Cin,
                 median(0, 1), median(1, 2), median(2, 3), median(3, 4), median(4, 5), median(5, 6), median(6, 7), median(0, 7),
                 median(8, 15) * 0.01, life_mem / life_wall * 100.0, (double)(hi - lo) * 0.01, life_wall * 0.01 / 256.0);
     }
@@ -1310,6 +1383,7 @@ void bf16_set_dma(int v) { g_bf16_dma = v; }
 void bf16_set_patch(int v) { g_bf16_stages = v >= 10 ? 3 : 4; g_bf16_patch = v % 10; }
 void bf16_set_fused_stem(int on) { g_bf16_fused_stem = on; }
 void bf16_set_lean_epi(int on) { g_bf16_lean_epi = on; }
+void bf16_set_persist(int v) { g_bf16_persist = v; }
 void bf16_set_linear_dma(int v) { g_bf16_linear_dma = v; }
 void bf16_set_chunk(int images, int min_mb) { g_bf16_chunk = images; g_bf16_chunk_mb = min_mb; }
 #ifdef RPG_PROBE_WS64
@@ -1449,6 +1523,8 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
         } else if (cout > 128) {
             done = launch_patch<256, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s);
         } else if (cout > 64 && big) {
+            // (the persistent form of this tile was built and measured slower -- 141 -> 179 us: at 256 VGPRs the next tile's piece
+            // addresses, computed in front of the last chunk with the accumulators live, spill 65-113 registers)
             done = (g_bf16_stages != 3 && launch_patch<512, 128, 4, 2, 4>(a, wp, n, (int)M, cout, ep, s)) ||
                    launch_patch<512, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s);
         } else if (g_bf16_patch >= 2 || big) {
@@ -1457,7 +1533,8 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
             // With the lean epilogue of round 4 the order flipped where it matters: 216-223 / 229-239 us (without / with residual)
             // against 214-215 / 246-248, and the whole configs[2] step gains 2.4 % (12.79 -> 13.10 k graphs/s, two streams:
             // profiles/r4_bf16_epilogue_experiments.txt) -- a quarter of the L2 -> LDS traffic leaves more of the chip to the other stream.
-            done = (g_bf16_stages != 3 && launch_patch<512, 64, 8, 1, 4>(a, wp, n, (int)M, cout, ep, s)) ||
+            done = (g_bf16_persist && g_bf16_stages != 3 && launch_patch<512, 64, 8, 1, 4, true>(a, wp, n, (int)M, cout, ep, s)) ||
+                   (g_bf16_stages != 3 && launch_patch<512, 64, 8, 1, 4>(a, wp, n, (int)M, cout, ep, s)) ||
                    launch_patch<512, 64, 8, 1, 3>(a, wp, n, (int)M, cout, ep, s);
         }
     }

@@ -121,6 +121,31 @@ def test_bf16_encoder_forward_vs_fp32_oracle(dev):
     assert torch.equal(a2, a32) and torch.equal(r2, r32)
 
 
+def test_bf16_forward_with_persistent_layer1_is_bit_identical(dev):
+    """RPG_TUNE_BF16_PERSIST = 1 inside the model: 6 graphs x 8 nodes x 224x224 put 294 tiles of 512 pixels on layer 1 (more than one
+    round of the 256 CUs: the persistent form is dispatched); the poses equal the default dispatch bit for bit."""
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd import ops
+    from relpose_gnn_amd.graph import fc_batch
+    from relpose_gnn_amd.posenet import PoseNetX_R2
+    from relpose_gnn_amd.resnet import resnet34
+    D = 2048
+    m = PoseNetX_R2(resnet34(), droprate=0.0, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D,
+                    input_img_height=224, use_gnn=True, knn=-1, use_AP=True, gnn_recursion=2)
+    m.load_state_dict(S.synth_state_dict(S.posenet_r2_param_shapes(D, D, D), seed=1))
+    m = m.to(dev).eval()
+    m.encoder_dtype = "bf16"
+    d = fc_batch(S.synth_images(48, 224, 224, seed=9), 8).to(dev)
+    a0, r0, _ = m(d)
+    ops.set_tuning(ops.TUNE_BF16_PERSIST, 1)
+    try:
+        a1, r1, _ = m(d)
+    finally:
+        ops.set_tuning(ops.TUNE_BF16_PERSIST, 0)
+    assert torch.equal(a0, a1) and torch.equal(r0, r1)
+    assert bool(torch.isfinite(a1).all()) and float(a1.abs().max()) > 0
+
+
 @pytest.mark.parametrize("m,k,n_out,gather", [(333, 192, 100, 2), (1792, 2048, 768, 0), (130, 256, 2048, 1), (64, 72, 40, 0)])
 def test_linear_bf16(dev, m, k, n_out, gather):
     """rpg_f32_to_bf16 + rpg_linear_bf16 (bf16 inputs / weights, fp32 accumulate / bias / residual / output; plain and
@@ -250,6 +275,24 @@ def test_conv_bf16_dma_configs(dev, cfg, n, h, w, cin, cout, k, stride, pad, res
     (300, 7, 7, 512, 512, False, True),     # 58 x 2 tiles of 256 x 256 is too few -> 256 x 128; 53-KB patches: three stages only
 ])
 def test_conv3x3_bf16_patch_kernel(dev, mode, n, h, w, cin, cout, res, relu):
+    _patch_kernel_case(dev, mode, 0, n, h, w, cin, cout, res, relu)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,res,relu", [
+    (70, 56, 56, 64, 64, True, True),       # layer 1: 429 tiles of 512 rows on 256 CUs (1.7 rounds: workgroups with 1 and with 2 tiles), ragged last tile
+    (171, 56, 56, 64, 64, False, True),     # 1048 tiles: 4.1 rounds, the stage rotation of the four-stage form wraps across tiles
+    (100, 40, 40, 64, 64, True, True),      # 48 slots per row, 18 patch rows: 313 tiles, ragged
+    (300, 13, 17, 64, 64, True, False),     # small odd images: tiles span 3 images, 130 tiles only -> not eligible, one workgroup per tile
+    (200, 28, 28, 128, 40, False, True),    # 307 tiles, 4 chunks per tile (the wrap happens in front of chunk 3), ragged N = 40 inside the one channel tile
+])
+def test_conv3x3_bf16_patch_kernel_persistent(dev, n, h, w, cin, cout, res, relu):
+    """RPG_TUNE_BF16_PERSIST = 1: the persistent form of the patch kernel on <= 64 output channels (one workgroup per CU
+    walks its tiles, the next tile's first patch chunk and weights load during the current tile's last chunk and epilogue, slabs
+    beside patch buffer 1) against F.conv2d, and bit-identical to the one-workgroup-per-tile form (same MFMA order per tile)."""
+    _patch_kernel_case(dev, 2, 1, n, h, w, cin, cout, res, relu)
+
+
+def _patch_kernel_case(dev, mode, persist, n, h, w, cin, cout, res, relu):
     """The patch kernel of the bf16 encoder (3x3 / stride 1 / pad 1 with the input patch resident in LDS; RPG_TUNE_BF16_PATCH = 2:
     every eligible size, tile by output width -- 512 x 64, 512 x 128, 256 x 128, 256 x 256; 3: the 256 x 128 tile everywhere; 12:
     as 2 but never the four-weight-stage form) against F.conv2d on the same bf16 inputs in fp32:
@@ -268,12 +311,19 @@ def test_conv3x3_bf16_patch_kernel(dev, mode, n, h, w, cin, cout, res, relu):
     if relu:
         ref = F.relu(ref)
     ops.set_tuning(ops.TUNE_BF16_PATCH, mode)
+    args = (x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev), scale.to(dev), shift.to(dev),
+            None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev))
     try:
-        y = ops.conv2d_bn_act_nhwc_bf16(x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev),
-                                        scale.to(dev), shift.to(dev), None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev),
-                                        stride=1, pad=1, relu=relu)
+        ops.set_tuning(ops.TUNE_BF16_PERSIST, 0)
+        y = ops.conv2d_bn_act_nhwc_bf16(*args, stride=1, pad=1, relu=relu)
+        if persist:
+            ops.set_tuning(ops.TUNE_BF16_PERSIST, 1)
+            y1 = ops.conv2d_bn_act_nhwc_bf16(*args, stride=1, pad=1, relu=relu)
+            assert torch.equal(y1, y)
+            y = y1
     finally:
         ops.set_tuning(ops.TUNE_BF16_PATCH, 1)
+        ops.set_tuning(ops.TUNE_BF16_PERSIST, 0)
     got = y.float().cpu().permute(0, 3, 1, 2)
     assert rel_err(got, ref) < 1e-2
     assert float((got - ref).abs().mean() / ref.abs().mean().clamp(min=1e-30)) < 3e-3     # bf16 output rounding only
