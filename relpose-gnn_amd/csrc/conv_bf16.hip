@@ -1209,7 +1209,7 @@ bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, c
         // persistent form: one workgroup per CU, more than one round of tiles, one channel tile (the weight offsets carry over), the
         // epilogue slabs beside patch buffer 1 (kernel comment)
         grid = rpg::num_cus();
-        if (!ep.lean || a.tiles_n != 1 || a.n_tiles <= grid || (long)a.n_tiles * BM >= (1L << 31)) return false;
+        if (!ep.lean || a.tiles_n != 1 || a.n_tiles <= grid || ((long)a.n_tiles + grid) * BM >= (1L << 31)) return false;      // (the tile after the last is still an int)
         lds = a.patch_bytes + NS * BN * 64 + 1024 + (a.patch_bytes > slab ? a.patch_bytes : slab);
     }
     if (a.n_pieces > 64 || lds > 160 * 1024 || lds < slab) return false;
