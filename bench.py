@@ -267,8 +267,51 @@ def other_configs(model, args, dev):
                                      f"images in pageable host memory -> evaluate_stream (micro-batch {mb}, pinned double-buffered H2D on a "
                                      "copy stream, D2H + test.py:213-251 post-processing per graph included); the 4- / 8-GPU sharding is "
                                      "tools/eval_stream.py under torch.distributed.run"}
+        # single graph at the evaluation shape (what the unmodified testing/test.py:192-211 loop feeds: batch_size=1, 8 x 256x341)
+        model.encoder_dtype = model.gnn_dtype = "f32"
+        d1 = fc_batch(torch.randn((NODES, 3 * h * w), generator=torch.Generator(device=dev).manual_seed(5), device=dev), NODES)
+        for _ in range(5):
+            model(d1)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(30):
+            t0 = time.perf_counter()
+            a1, r1, _ = model(d1)
+            r1.cpu()                                              # test.py:214: the caller's own synchronisation point
+            ts.append(time.perf_counter() - t0)
+        out["latency_1graph_256x341"] = {"ms": round(1e3 * sorted(ts)[len(ts) // 2], 4), "graphs_per_s": round(1.0 / sorted(ts)[len(ts) // 2], 1),
+                                         "what": "one 8-node 256x341 graph per forward + .cpu() of the relative poses per call (median of 30): "
+                                                 "what INTEGRATION.md's 3-line edit of testing/test.py yields per iteration, fp32"}
     finally:
         model.encoder_dtype, model.gnn_dtype, model.hip_streams, model.input_img_height = "f32", "f32", args.streams, IMG
+    return out
+
+
+def reference_default_flags(model_factory, args, dev, x, base_ms):
+    """What the reference's default CLI actually runs (testing/test.py:308-309: --knn 4 --droprate 0.5), timed on the headline
+    workload (32 graphs x 8 x 224x224, fp32, inputs resident): `knn=4` builds the kNN graph per stream slot from the slot's
+    encoder output, `droprate=0.5` adds the always-on F.dropout + the heads per slot (posenet.py:1047-1048,1073-1086)."""
+    from relpose_gnn_amd.graph import fc_batch
+    out = {}
+    data = fc_batch(x, NODES)
+    steps = max(args.steps, 5)
+    for name, kw in (("knn4", {"knn": 4, "droprate": 0.0}), ("droprate0.5", {"knn": -1, "droprate": 0.5}),
+                     ("knn4_droprate0.5", {"knn": 4, "droprate": 0.5})):
+        m = model_factory(**kw)
+        m.hip_streams = args.streams
+        for _ in range(3):
+            _, rel, ei = m(data)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _, rel, ei = m(data)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert bool(torch.isfinite(rel).all()) and rel.shape[0] == ei.shape[1]
+        ms = 1e3 * dt / steps
+        out[name] = {"value": round(x.shape[0] // NODES * steps / dt, 1), "unit": "graphs/s", "ms_per_step": round(ms, 3),
+                     "edges_per_graph": int(ei.shape[1]) // (x.shape[0] // NODES), "over_headline_step": round(ms / base_ms, 4)}
+        del m
     return out
 
 
@@ -334,11 +377,15 @@ def main():
     from relpose_gnn_amd.shard import gather_rows
 
     D = 2048
-    model = PoseNetX_R2(resnet34(), droprate=0.0, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D,
-                        input_img_height=IMG, use_gnn=True, knn=-1, use_AP=True, gnn_recursion=2)
     sd = S.synth_state_dict(S.posenet_r2_param_shapes(D, D, D), seed=1)
-    model.load_state_dict(sd)
-    model = model.to(dev).eval()
+
+    def model_factory(knn=-1, droprate=0.0):
+        m = PoseNetX_R2(resnet34(), droprate=droprate, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D,
+                        input_img_height=IMG, use_gnn=True, knn=knn, use_AP=True, gnn_recursion=2)
+        m.load_state_dict(sd)
+        return m.to(dev).eval()
+
+    model = model_factory()
     model.hip_streams = args.streams
     if args.schedule:
         model.stream_schedule = [tuple(int(v) for v in part.split(":")) for part in args.schedule.split(",")]
@@ -447,6 +494,12 @@ def main():
             others = other_configs(model, args, dev)
         except Exception as exc:                                         # a secondary leg must not take the headline down
             others = {"error": f"{type(exc).__name__}: {exc}"}
+    ref_flags = None
+    if rank == 0 and world == 1 and args.encoder_dtype == "f32" and args.graphs == 32 and not args.no_other_configs:
+        try:
+            ref_flags = reference_default_flags(model_factory, args, dev, x, 1e3 * elapsed / args.steps)
+        except Exception as exc:
+            ref_flags = {"error": f"{type(exc).__name__}: {exc}"}
     if under_launcher:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -564,6 +617,31 @@ def main():
                                                     "per call with a host synchronisation after each / per call when 40 calls are streamed")
         if others is not None:
             line["other_configs"] = others
+            # compact copy INSIDE `config` (the driver's record keeps `config` whole): [graphs/s, ms per step | seconds, roofline frac]
+            sec = {}
+            for short, key in (("c2_bf16enc", "configs2_bf16_encoder"), ("c2_bf16all", "configs2_bf16_all"),
+                               ("c3_stream_fp32", "configs3_eval_stream_1gpu_host_fp32"), ("c4_stream_bf16", "configs4_eval_stream_1gpu_host_bf16")):
+                v = others.get(key)
+                if isinstance(v, dict):
+                    sec[short] = [v.get("value"), v.get("ms_per_step", v.get("seconds")), (v.get("roofline") or {}).get("frac")]
+            if isinstance(others.get("latency_1graph_256x341"), dict):
+                sec["lat1_256x341_ms"] = others["latency_1graph_256x341"]["ms"]
+            if "error" in others:
+                sec["error"] = others["error"]
+            if lat1 is not None:
+                sec["lat1_ms"] = lat1["latency_1graph_ms"]
+            if isinstance(ref_flags, dict):
+                for kk, v in ref_flags.items():
+                    sec["c1_" + kk] = [v.get("value"), v.get("ms_per_step"), v.get("over_headline_step")] if isinstance(v, dict) else v
+            line["config"]["secondary"] = sec
+        if ref_flags is not None:
+            line["reference_default_flags"] = ref_flags
+        import hashlib
+        from relpose_gnn_amd import _lib as _L
+        with open(_L.LIB_PATH, "rb") as fh:
+            line["config"]["loaded_library"] = {"path": os.path.relpath(_L.LIB_PATH, ROOT) if _L.LIB_PATH.startswith(ROOT) else _L.LIB_PATH,
+                                                "sha256_12": hashlib.sha256(fh.read()).hexdigest()[:12],
+                                                "env_override": bool(os.environ.get("RPG_HIP_LIB"))}
         line["rccl_ranks_seen"] = dist.get_world_size() if under_launcher else None
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line

@@ -343,6 +343,10 @@ int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
                                      loaded during the current tile's last chunk and epilogue).  The kernel is 10 % (in the model) to 15 % (stand-alone)
                                      faster; the default two-stream step is 2 % SLOWER with it (resident workgroups leave the other stream no gaps), so
                                      the default is 0 = one workgroup per tile.  For single-stream use */
+#define RPG_TUNE_FOLD_K 26          /* fp32 Linears (rpg_linear_gather_f32 and the GNN composite): two-level accumulation -- the v_mfma_f32_32x32x2_f32
+                                     accumulator is folded into a second one and restarted every `value` of K (a multiple of 64; default 256; 0 = one
+                                     sequential chain over all of K as in rounds 1-4).  Summation order only: cuts the rounding noise of the K = 2048..4096
+                                     GNN Linears (reference: addmm in my_gnn_layer.py:236-239,304-311 through oneDNN's blocked sums) */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -25,6 +25,7 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -74,6 +75,7 @@ struct GatherArgs {
     const int64_t* idx[3];
     int ld[3];
     int w0, w01, K;    // segment boundaries along k: [0,w0) [w0,w01) [w01,K)
+    int fold_k;        // two-level accumulation: fold the accumulator every fold_k of K (0 = never); buffer-loader kernels on 32x32 wave tiles
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -105,6 +107,7 @@ int g_epi_lds = 1;
 int g_streamk = 1;
 int g_gnn_split = 1;
 int g_gnn_fuse_agg = 1;
+int g_fold_k = 256;                  // RPG_TUNE_FOLD_K: two-level accumulation of the Linears (gemm_engine.inc), 0 = one sequential chain
 int SK_MIN_ITS = 8;                  // at least this many k-steps per stream-K workgroup (RPG_TUNE_SK_MIN_ITS)
 constexpr int SK_MIN_NK = 32;        // tiles with fewer k-steps are not worth splitting (fix-up traffic dominates)
 
@@ -235,7 +238,9 @@ struct GatherKind {
 template <class Kind, class Args>
 int launch_tiles(const Args& args, const float* Wt, int ldw, int M, int N, int K, const Epilogue& ep, hipStream_t s,
                  int seg_align) {
-    const TileShape t = pick_tile(M, N, K);
+    TileShape t = pick_tile(M, N, K);
+    // two-level accumulation lives in the 32x32 wave tiles (128x64 on 8 waves): a Linear long enough to need it does not take the 128x128 tile
+    if (std::is_same<Kind, GatherKind>::value && g_fold_k > 0 && g_force_tile < 0 && t == TILE_128x128 && K >= 2 * g_fold_k) t = TILE_128x64;
     const int bk = g_bk ? g_bk : (((t == TILE_128x128 || t == TILE_128x64) && K >= 256) ? 32 : 16);
     // 16-byte epilogue accesses need 4-column groups: N % 4 == 0 and 16-byte aligned rows
     const bool vec_ok = (N % 4 == 0) && (ep.ldc % 4 == 0) && rpg::aligned16(ep.out) &&
@@ -330,6 +335,7 @@ int launch_linear(const GatherSrc& src, const float* weight, const float* bias, 
     a.w0 = src.width[0];
     a.w01 = src.n >= 2 ? src.width[0] + src.width[1] : K;
     a.K = K;
+    a.fold_k = g_fold_k;
     Epilogue ep{nullptr, bias, residual, out, n_out, relu};
     ep.out_relu = out_relu;
     if (out_relu && !aligned16(out_relu)) return RPG_ERR_BAD_ARG;
@@ -404,6 +410,7 @@ extern "C" int rpg_set_tuning(int key, int value) {
             return RPG_OK;
         case RPG_TUNE_GNN_SPLIT: g_gnn_split = value != 0; return RPG_OK;
         case RPG_TUNE_GNN_FUSE_AGG: g_gnn_fuse_agg = value != 0; return RPG_OK;
+        case RPG_TUNE_FOLD_K: if (value < 0 || (value % 64)) return RPG_ERR_BAD_ARG; g_fold_k = value; return RPG_OK;
         case RPG_TUNE_FAST_LOADER: g_fast = value != 0; return RPG_OK;
         case RPG_TUNE_WAVES8: g_waves8 = value != 0; return RPG_OK;
         case RPG_TUNE_WINO_SPLIT: if (value < 0 || value > 96) return RPG_ERR_BAD_ARG; rpg::wino_split_set(value); return RPG_OK;

@@ -83,11 +83,21 @@ def conv3x3_wino43_bn_act_nhwc(x: torch.Tensor, u: torch.Tensor, scale: Optional
     per = int(L.lib().rpg_wino43_weights_floats(1, 1))            # 18 (42 in a probe build with the nested kernel)
     if u.dim() not in (1, 4) or u.numel() == 0 or u.numel() % (per * cin) or (u.dim() == 4 and tuple(u.shape[::2]) != (6, 3)):
         raise ValueError("u must come from wino43_transform_weights: [6][Cout][3][Cin]")
-    cout = u.numel() // (per * cin)
+    if u.dim() == 4:
+        if u.shape[3] != cin:
+            raise ValueError(f"channel mismatch: x has {cin} channels, u was built for {u.shape[3]}")
+        cout = u.shape[1]
+    else:                                                          # flat buffer of a probe build: Cout from its size
+        cout = u.numel() // (per * cin)
     y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
     scale = None if scale is None else _req(scale, "scale")
     shift = None if shift is None else _req(shift, "shift")
     residual = None if residual is None else _req(residual, "residual")
+    for name, t in (("scale", scale), ("shift", shift)):
+        if t is not None and t.numel() != cout:
+            raise ValueError(f"{name} must have Cout = {cout} elements, got {t.numel()}")
+    if residual is not None and tuple(residual.shape) != (n, h, w, cout):
+        raise ValueError("residual shape mismatch")
     L.check(L.lib().rpg_conv3x3_wino43_bn_act_nhwc_f32(_p(x), _p(u), _p(scale), _p(shift), _p(residual), _p(y), n, h, w, cin,
                                                         cout, int(relu), _stream()), "conv3x3_wino43_bn_act_nhwc")
     return y
@@ -210,9 +220,10 @@ def graph_prepare(edge_index: torch.Tensor, n: int) -> Dict[str, torch.Tensor]:
     return {"ends": ends, "rowptr": rowptr, "perm": perm, "status": status}
 
 
-def knn_graph(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """torch_cluster.knn_graph(x, k, batch, loop=False): [2, E] int64, row 0 = neighbour, row 1 = query node.
-    Synchronises once to learn E (E = n*k unless a graph has fewer than k+1 nodes or duplicate rows)."""
+def knn_graph_launch(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Enqueue the kNN graph build on the current stream WITHOUT synchronising: returns (edge buffer [2, n*(k+1)] int64,
+    meta int32 [2] = (E, graphs-too-large flag), both on the device).  The first E columns of the buffer are the edges once
+    the stream has run; knn_graph() below reads E right away, PoseNetX_R2's multi-stream path reads it behind an event."""
     x = _req(x, "x")
     n, d = x.shape
     batch = None if batch is None else _req(batch, "batch", torch.int64)
@@ -223,6 +234,13 @@ def knn_graph(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None) -> 
     meta = torch.zeros(2, dtype=torch.int32, device=x.device)
     L.check(L.lib().rpg_knn_graph_f32(_p(x), _p(batch), n, d, k, _p(ei), _p(cand), _p(cnt), meta.data_ptr(),
                                       meta.data_ptr() + 4, _stream()), "knn_graph")
+    return ei, meta
+
+
+def knn_graph(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """torch_cluster.knn_graph(x, k, batch, loop=False): [2, E] int64, row 0 = neighbour, row 1 = query node.
+    Synchronises once to learn E (E = n*k unless a graph has fewer than k+1 nodes or duplicate rows)."""
+    ei, meta = knn_graph_launch(x, k, batch)
     total, bad = (int(v) for v in meta.tolist())
     if bad:
         raise ValueError("knn_graph: a graph has more than 2048 nodes (unsupported)")
@@ -292,10 +310,13 @@ def attention_aggregate(gtp: torch.Tensor, msg: torch.Tensor, rowptr: torch.Tens
     return ybar, mbar
 
 
-def pose_heads(x: torch.Tensor, w6: torch.Tensor, b6: torch.Tensor) -> torch.Tensor:
+def pose_heads(x: torch.Tensor, w6: torch.Tensor, b6: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     x, w6, b6 = _req(x, "x"), _req(w6, "w6"), _req(b6, "b6")
     r, d = x.shape
-    out = torch.empty((r, 6), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((r, 6), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (r, 6) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+        raise ValueError("pose_heads: out must be a contiguous fp32 [rows, 6] tensor on x's device")
     L.check(L.lib().rpg_pose_heads_f32(_p(x), _p(w6), _p(b6), r, d, _p(out), _stream()), "pose_heads")
     return out
 
@@ -317,7 +338,7 @@ def release_scratch() -> None:
     L.check(L.lib().rpg_release_scratch(), "release_scratch")
 
 
-TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST, TUNE_FUSED_STEM, TUNE_WAVES8, TUNE_WINO_SHORT, TUNE_GNN_FUSE_AGG, TUNE_WINO_PERSIST, TUNE_BF16_TILE, TUNE_BF16_DMA, TUNE_BF16_PATCH, TUNE_BF16_WS64, TUNE_SK_MIN_ITS, TUNE_INKERNEL_FIXUP, TUNE_BF16_CHUNK, TUNE_WINO2D, TUNE_BF16_LEAN_EPI, TUNE_BF16_LINEAR_DMA, TUNE_BF16_PERSIST = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25
+TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST, TUNE_FUSED_STEM, TUNE_WAVES8, TUNE_WINO_SHORT, TUNE_GNN_FUSE_AGG, TUNE_WINO_PERSIST, TUNE_BF16_TILE, TUNE_BF16_DMA, TUNE_BF16_PATCH, TUNE_BF16_WS64, TUNE_SK_MIN_ITS, TUNE_INKERNEL_FIXUP, TUNE_BF16_CHUNK, TUNE_WINO2D, TUNE_BF16_LEAN_EPI, TUNE_BF16_LINEAR_DMA, TUNE_BF16_PERSIST, TUNE_FOLD_K = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26
 
 
 def set_tuning(key: int, value: int) -> None:

@@ -299,19 +299,25 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         _L.check(rc, "gnn_forward")
 
     @staticmethod
-    def _graph_sizes(data, n_total: int, e_total: int):
+    def _graph_sizes(data, n_total: int, e_total: Optional[int]):
         """(nodes per graph, edges per graph) as host lists, or None.  Sources, cheapest first: this package's
         ``Batch.graph_sizes``; the host-side slice tables a ``torch_geometric`` ``Batch`` keeps from collation
         (``_slice_dict`` in PyG 2.x, ``__slices__`` in 1.x: cumulative offsets, never moved to the GPU -- this is what the
         reference's DataLoader hands over, testing/test.py:193); ``data.ptr`` / ``data.batch`` (device tensors: one small
         device-to-host copy BEFORE any kernel of this call is enqueued)."""
+        nodes_only = e_total is None          # kNN path: data.edge_index is replaced, only the node ranges are needed
         gs = getattr(data, "graph_sizes", None)
         if gs is not None:
+            if nodes_only:
+                return (gs[0], [0] * len(gs[0])) if sum(gs[0]) == n_total else None
             return gs if sum(gs[0]) == n_total and sum(gs[1]) == e_total else None
         for attr in ("_slice_dict", "__slices__"):
             sl = getattr(data, attr, None)
-            if isinstance(sl, dict) and "x" in sl and "edge_index" in sl:
+            if isinstance(sl, dict) and "x" in sl and (nodes_only or "edge_index" in sl):
                 cn = [int(v) for v in torch.as_tensor(sl["x"]).tolist()]
+                if nodes_only:
+                    ok = len(cn) >= 2 and cn[0] == 0 and cn[-1] == n_total
+                    return ([b - a for a, b in zip(cn, cn[1:])], [0] * (len(cn) - 1)) if ok else None
                 ce = [int(v) for v in torch.as_tensor(sl["edge_index"]).tolist()]
                 if len(cn) == len(ce) >= 2 and cn[0] == 0 and ce[0] == 0 and cn[-1] == n_total and ce[-1] == e_total:
                     return ([b - a for a, b in zip(cn, cn[1:])], [b - a for a, b in zip(ce, ce[1:])])
@@ -326,6 +332,8 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
             return None
         if sum(nodes) != n_total or len(nodes) < 2 or not torch.is_tensor(batch) or batch.numel() != n_total:
             return None
+        if nodes_only:
+            return (nodes, [0] * len(nodes))
         ei = data.edge_index
         gid = batch[ei[0]]                                     # graph of every edge (PyG keeps a graph's edges together)
         if e_total > 1 and bool((gid[1:] < gid[:-1]).any()):
@@ -333,8 +341,9 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         edges = [int(v) for v in torch.bincount(gid, minlength=len(nodes)).tolist()]
         return (nodes, edges) if sum(edges) == e_total else None
 
-    def _partition(self, data, n_total: int, e_total: int):
-        """Contiguous groups of whole graphs, one per stream: [(n0, n1, e0, e1), ...] or None (single stream)."""
+    def _partition(self, data, n_total: int, e_total: Optional[int]):
+        """Contiguous groups of whole graphs, one per stream: [(n0, n1, e0, e1, slot), ...] or None (single stream).
+        ``e_total=None``: the caller replaces ``data.edge_index`` (kNN graph) -- only the node ranges matter then."""
         parts = min(int(self.hip_streams), 8)                  # one bad-edge counter per slot (self._status)
         if parts < 2:
             return None
@@ -392,10 +401,15 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
         self._pack_gnn()
         self._enc.ensure_packed(self.feature_extractor.state_dict, "", x.device)
         self._status_buffers(x.device)
-        fast = self.use_AP and not self.use_attention and k is None and self.knn <= 0 and not self.droprate > 0
-        parts = self._partition(data, x.size(0), edge_index.size(1)) if fast else None
+        # The multi-stream schedule serves the reference's default CLI flags too (round 5; testing/test.py:308-309: --knn 4
+        # --droprate 0.5): the kNN graph is built per stream slot from that slot's encoder output, dropout + heads run per slot.
+        batch_t = getattr(data, "batch", None)
+        knn_ok = self.knn <= 0 or (torch.is_tensor(batch_t) and batch_t.dtype == torch.int64 and batch_t.device == x.device
+                                   and batch_t.dim() == 1 and batch_t.numel() == x.size(0))
+        fast = self.use_AP and not self.use_attention and k is None and knn_ok and not (self.knn > 0 and self._gnn_dtype == "bf16")
+        parts = self._partition(data, x.size(0), edge_index.size(1) if self.knn <= 0 else None) if fast else None
         if parts is not None and edge_index.dtype == torch.int64 and edge_index.dim() == 2 and edge_index.is_contiguous():
-            return self._forward_streams(lib, x, edge_index, parts)
+            return self._forward_streams(lib, x, edge_index, parts, batch_t)
         feat = self._encode_small(x)                                              # posenet.py:1037
 
         n, d = feat.shape
@@ -472,33 +486,88 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
             cur.wait_stream(st)
         return feat
 
-    def _forward_streams(self, lib, x, edge_index, parts):
-        """Fast path (use_AP, no kNN / dropout / extra attention) on ``len(parts)`` concurrent streams."""
+    def _forward_streams(self, lib, x, edge_index, parts, batch=None):
+        """use_AP / no extra attention / no explicit k, on ``len(parts)`` concurrent streams.  With ``knn > 0`` (the reference's
+        default CLI, testing/test.py:308) every slot builds the kNN graph of ITS graphs from its own encoder output
+        (posenet.py:1047-1048; graphs are independent, so the per-slot edge lists concatenate to the whole-batch list) and the
+        host learns each slot's edge count behind an event on that slot's stream -- the other slots' encoders keep the GPU
+        busy meanwhile -- before it enqueues the slot's GNN.  With ``droprate > 0`` the always-on dropout and the heads
+        (posenet.py:1073-1086) run per slot on the slot's stream."""
         dev = x.device
-        n_total, e_total = x.size(0), edge_index.size(1)
+        n_total = x.size(0)
+        knn = int(self.knn) if self.knn > 0 else 0
+        drop = self.droprate > 0
         n_slots = 1 + max(p[4] for p in parts)
         while len(self._streams) < n_slots:
             self._streams.append(torch.cuda.Stream(device=dev))
         cur = torch.cuda.current_stream()
         abs_pose = torch.empty((n_total, 6), dtype=torch.float32, device=dev)
-        rel_pose = torch.empty((e_total, 6), dtype=torch.float32, device=dev)
         status = self._status
         ready = torch.cuda.Event()
         ready.record(cur)
-        base = edge_index.data_ptr()
         for st in self._streams[:n_slots]:
             st.wait_event(ready)
-        for gi, (n0, n1, e0, e1, slot) in enumerate(parts):
+        d = self.feature_extractor.fc.out_features
+        t = self._gnn_packed
+
+        def heads(feat, n0, n1, ei_ptrs, node_off, e, rel_out, slot, wkey):
+            node_f = torch.empty((n1 - n0, d), dtype=torch.float32, device=dev) if drop else None
+            edge_f = torch.empty((e, d), dtype=torch.float32, device=dev) if drop else None
+            self._gnn_call(lib, feat, ei_ptrs[0], ei_ptrs[1], node_off, n1 - n0, e, abs_pose[n0:n1], rel_out, node_f, edge_f,
+                           status[slot:slot + 1], wkey)
+            if drop:                                                              # posenet.py:1073-1075 (always on)
+                ops.pose_heads(F.dropout(node_f, p=self.droprate), t[18], t[19], out=abs_pose[n0:n1])
+                ops.pose_heads(F.dropout(edge_f, p=self.droprate), t[20], t[21], out=rel_out)
+                for buf in (node_f, edge_f):
+                    buf.record_stream(torch.cuda.current_stream())
+
+        if not knn:
+            e_total = edge_index.size(1)
+            rel_pose = torch.empty((e_total, 6), dtype=torch.float32, device=dev)
+            base = edge_index.data_ptr()
+            for gi, (n0, n1, e0, e1, slot) in enumerate(parts):
+                st = self._streams[slot]
+                with torch.cuda.stream(st):
+                    # workspaces are per (slot, position in the slot's queue): groups of a slot run in order, so they could share,
+                    # but a different shape would re-allocate every call
+                    wkey = (slot, gi)
+                    feat = self._enc.run(self.feature_extractor.state_dict, "", x[n0:n1], slot=wkey)
+                    heads(feat, n0, n1, (base + 8 * e0, base + 8 * (e_total + e0)), n0, e1 - e0, rel_pose[e0:e1], slot, wkey)
+                    feat.record_stream(st)
+            for st in self._streams[:n_slots]:
+                cur.wait_stream(st)
+            self._publish_status()
+            return abs_pose, rel_pose, edge_index
+
+        # ---- knn > 0: phase 1 = encoder + kNN build per slot (no host wait), phase 2 = GNN per slot once its edge count is in
+        pend = []
+        for gi, (n0, n1, _, _, slot) in enumerate(parts):
             st = self._streams[slot]
             with torch.cuda.stream(st):
-                # workspaces are per (slot, position in the slot's queue): groups of a slot run in order, so they could share,
-                # but a different shape would re-allocate every call
                 wkey = (slot, gi)
                 feat = self._enc.run(self.feature_extractor.state_dict, "", x[n0:n1], slot=wkey)
-                self._gnn_call(lib, feat, base + 8 * e0, base + 8 * (e_total + e0), n0, n1 - n0, e1 - e0, abs_pose[n0:n1],
-                               rel_pose[e0:e1], None, None, status[slot:slot + 1], wkey)
-                feat.record_stream(st)
+                ei_buf, meta = ops.knn_graph_launch(feat, knn, batch[n0:n1])
+                meta_h = torch.empty(2, dtype=torch.int32).pin_memory()
+                meta_h.copy_(meta, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                pend.append((feat, ei_buf, meta, meta_h, ev, wkey))
+        rels, eis = [], []
+        for (n0, n1, _, _, slot), (feat, ei_buf, meta, meta_h, ev, wkey) in zip(parts, pend):
+            ev.synchronize()
+            total, bad = int(meta_h[0]), int(meta_h[1])
+            if bad:
+                raise ValueError("knn_graph: a graph has more than 2048 nodes (unsupported)")
+            st = self._streams[slot]
+            with torch.cuda.stream(st):
+                cap = ei_buf.size(1)
+                rel = torch.empty((total, 6), dtype=torch.float32, device=dev)
+                heads(feat, n0, n1, (ei_buf.data_ptr(), ei_buf.data_ptr() + 8 * cap), 0, total, rel, slot, wkey)
+                eis.append(ei_buf[:, :total] + n0)                                # node ids of the whole batch (posenet.py:1048)
+                rels.append(rel)
+                for buf in (feat, ei_buf, meta):
+                    buf.record_stream(st)
         for st in self._streams[:n_slots]:
             cur.wait_stream(st)
         self._publish_status()
-        return abs_pose, rel_pose, edge_index
+        return abs_pose, torch.cat(rels), torch.cat(eis, dim=1)
