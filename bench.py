@@ -332,9 +332,21 @@ def spawn_ranks(n: int, script: str = None, argv=None) -> int:
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None
+    dec = json.JSONDecoder()
     for out in proc.stdout:
-        if out.lstrip().startswith("{") and '"metric"' in out:
-            line = out.strip()
+        # rank 0's line; the ranks share one pipe, so another rank's output may sit in front of / behind it on the same line
+        i = out.find('{"metric"')
+        obj = None
+        if i >= 0:
+            try:
+                obj, end = dec.raw_decode(out[i:])
+            except ValueError:
+                obj = None
+        if obj is not None:
+            line = out[i:i + end]
+            rest = (out[:i] + out[i + end:]).strip()
+            if rest:
+                sys.stderr.write(rest + "\n")
         else:
             sys.stderr.write(out)
     rc = proc.wait()
