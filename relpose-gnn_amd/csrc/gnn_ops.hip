@@ -188,79 +188,91 @@ __global__ __launch_bounds__(NT) void attention_rows_kernel(const float* __restr
 //   mean_e(att) = W mean_e(y) + (b + mean_e(msg))            (summation order changes only)
 // and the E-row Linear att.W becomes an N-row one.  This kernel produces the two means for a node directly:
 //   ybar[v][i] = (1/cnt) sum_{e -> v} y_e[i],   mbar[v][:] = (1/cnt) sum_{e -> v} msg[e][:] (+ bias if cnt > 0)
-// in ascending edge order (the order of torch_scatter's CPU kernel; mbar without bias is BIT-EXACT scatter-mean of msg),
-// so neither the per-edge y [E][C], nor att [E][D], nor a separate scatter launch exist any more.
-// Workgroup (node v, quarter s): 256 threads = 64 channels (i = 64 s + t % 64) x 4 j-quarters (wave = t / 64): a thread
-// accumulates exp(phi_i theta_j - m_i) (g_j) over its 64 j, the quarters are combined through LDS; threads 0..D/16-1
-// also carry one float4 column of mbar.  An isolated node (cnt = 0) gives zeros, like scatter-mean.
+// (mbar without bias is BIT-EXACT scatter-mean of msg: ascending edge order, the order of torch_scatter's CPU kernel), so
+// neither the per-edge y [E][C], nor att [E][D], nor a separate scatter launch exist any more.
+//
+// Round 5 form.  The kernel is bound by its 65,536 exponentials per edge (v_exp_f32 is quarter rate), so everything else is
+// taken off the vector unit's critical path: workgroup (node v, 64-channel quarter s) = 8 waves, and the node's incoming
+// EDGES ARE PROCESSED IN PARALLEL, ONE PER WAVE (round 4 walked them serially with three workgroup barriers each).  Lane = output
+// channel i; the wave's theta / g rows are wave-uniform, so they come through the SCALAR unit (s_load from the read-only
+// gtp: no LDS staging, no barrier, one scalar operand per VALU instruction).  Per (i, j): one v_fma (phi_i log2e theta_j -
+// m_i log2e, single rounding), v_exp_f32, v_add, v_fma.  m_i = max_j(phi_i theta_j) = phi_i * (phi_i >= 0 ? max theta :
+// min theta); softmax is shift invariant, so any m_i close to the maximum does.  The per-edge rows y_e meet in LDS and wave 0
+// adds them in ascending edge order (a node with more than 8 incoming edges: wave w takes edges w, w + 8, ... and the
+// wave partials are added in wave order).  Threads 0 .. D/16/quarters - 1 also carry one float4 column of mbar, all of the
+// node's message rows in flight at once.  An isolated node (cnt = 0) gives zeros, like scatter-mean.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void attention_aggregate_kernel(const float* __restrict__ gtp, const float4* __restrict__ msg,
-                                                                 const int* __restrict__ rowptr, const int* __restrict__ perm,
-                                                                 const float4* __restrict__ bias, int C, int d4,
-                                                                 float* __restrict__ ybar, float4* __restrict__ mbar) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // theta[C], g[C], red[8], part[2][4][64]
-    float* s_th = sm;
-    float* s_g = sm + C;
-    float* s_red = sm + 2 * C;
-    float* s_part = sm + 2 * C + 8;
-    const int v = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, wave = tid >> 6;
-    const int i = 64 * s + (tid & 63);                    // this thread's output channel (valid if < C)
+constexpr int AA_NT = 512, AA_W = AA_NT / 64;
+
+__global__ __launch_bounds__(AA_NT) void attention_aggregate_kernel(const float* __restrict__ gtp, const float4* __restrict__ msg,
+                                                                    const int* __restrict__ rowptr, const int* __restrict__ perm,
+                                                                    const float4* __restrict__ bias, int C, int d4,
+                                                                    float* __restrict__ ybar, float4* __restrict__ mbar) {
+    __shared__ float s_y[AA_W][64];
+    const int v = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = 64 * s + lane;                          // this lane's output channel (valid if < C)
     const int beg = rowptr[v], end = rowptr[v + 1];
     const int dq = (d4 + gridDim.y - 1) / gridDim.y;      // float4 columns of mbar per quarter
     const int mc = s * dq + tid;                          // this thread's mbar column (valid if tid < dq && mc < d4)
     const bool m_ok = tid < dq && mc < d4;
-    float yacc = 0.f;
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    // ---- mbar: ascending edge order, up to 8 rows in flight
     float4 macc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = beg; p < end; ++p) {
-        const int e = perm[p];
-        const float* row = gtp + (size_t)e * 3 * C;
-        __syncthreads();                                  // the previous row's LDS is consumed
+    if (m_ok) {
+        for (int p0 = beg; p0 < end; p0 += 8) {
+            float4 mv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                mv[t] = (p0 + t < end) ? msg[(size_t)perm[p0 + t] * d4 + mc] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (p0 + t < end) { macc.x += mv[t].x; macc.y += mv[t].y; macc.z += mv[t].z; macc.w += mv[t].w; }
+        }
+    }
+
+    // ---- attention rows: wave w takes edges beg + w, beg + w + 8, ...
+    float ysum = 0.f;
+    for (int p = beg + wave; p < end; p += AA_W) {
+        const int e = __builtin_amdgcn_readfirstlane(perm[p]);
+        const float* __restrict__ row = gtp + (size_t)e * 3 * C;      // wave-uniform: g | theta | phi
         float tmax = -INFINITY, tmin = INFINITY;
-        for (int j = tid; j < C; j += NT) {
-            const float th = row[C + j];
-            s_th[j] = th;
-            s_g[j] = row[j];
-            tmax = fmaxf(tmax, th);
-            tmin = fminf(tmin, th);
+        for (int j = 4 * lane; j < C; j += 256) {
+            const float4 th = *reinterpret_cast<const float4*>(row + C + j);
+            tmax = fmaxf(fmaxf(tmax, fmaxf(th.x, th.y)), fmaxf(th.z, th.w));
+            tmin = fminf(fminf(tmin, fminf(th.x, th.y)), fminf(th.z, th.w));
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             tmax = fmaxf(tmax, __shfl_xor(tmax, off));
             tmin = fminf(tmin, __shfl_xor(tmin, off));
         }
-        if ((tid & 63) == 0) { s_red[wave] = tmax; s_red[4 + wave] = tmin; }
-        if (m_ok) {
-            const float4 mv = msg[(size_t)e * d4 + mc];
-            macc.x += mv.x; macc.y += mv.y; macc.z += mv.z; macc.w += mv.w;
+        const float phi = (i < C) ? row[2 * C + i] : 0.f;
+        const float pl = phi * LOG2E;
+        const float nm = -(pl * (phi >= 0.f ? tmax : tmin));
+        float den0 = 0.f, num0 = 0.f, den1 = 0.f, num1 = 0.f;
+        const float* __restrict__ gr = row;
+        const float* __restrict__ tr = row + C;
+#pragma unroll 8
+        for (int j = 0; j < C; j += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(pl, tr[j], nm));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(pl, tr[j + 1], nm));
+            den0 += p0; num0 = __builtin_fmaf(p0, gr[j], num0);
+            den1 += p1; num1 = __builtin_fmaf(p1, gr[j + 1], num1);
         }
-        __syncthreads();
-        tmax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-        tmin = fminf(fminf(s_red[4], s_red[5]), fminf(s_red[6], s_red[7]));
-        float den = 0.f, num = 0.f;
-        if (i < C) {
-            const float phi = row[2 * C + i];
-            const float m = __fmul_rn(phi, (phi >= 0.f ? tmax : tmin));
-            const int jq = (C + 3) / 4, j0 = wave * jq, j1 = min(C, j0 + jq);
-            for (int j = j0; j < j1; ++j) {
-                // product and subtraction rounded separately (no FMA contraction), as the reference's matmul-then-softmax
-                const float pe = __expf(__fsub_rn(__fmul_rn(phi, s_th[j]), m));
-                den += pe;
-                num += pe * s_g[j];
-            }
-        }
-        s_part[wave * 64 + (tid & 63)] = den;
-        s_part[256 + wave * 64 + (tid & 63)] = num;
-        __syncthreads();
-        if (wave == 0 && i < C) {
-            const int l = tid & 63;
-            const float dsum = ((s_part[l] + s_part[64 + l]) + s_part[128 + l]) + s_part[192 + l];
-            const float nsum = ((s_part[256 + l] + s_part[320 + l]) + s_part[384 + l]) + s_part[448 + l];
-            yacc += nsum / dsum;
-        }
+        ysum += (num0 + num1) / (den0 + den1);
     }
+    s_y[wave][lane] = ysum;
+    __syncthreads();
     const int cnt = end - beg;
     const float dv = (float)(cnt > 0 ? cnt : 1);
-    if (wave == 0 && i < C) ybar[(size_t)v * C + i] = yacc / dv;
+    if (wave == 0 && i < C) {
+        float y = s_y[0][lane];
+#pragma unroll
+        for (int w = 1; w < AA_W; ++w) y += s_y[w][lane];
+        ybar[(size_t)v * C + i] = y / dv;
+    }
     if (m_ok) {
         float4 o = make_float4(macc.x / dv, macc.y / dv, macc.z / dv, macc.w / dv);
         if (bias && cnt > 0) {
@@ -501,9 +513,9 @@ extern "C" int rpg_attention_aggregate_f32(const float* gtp, const float* msg, c
         return RPG_ERR_BAD_ARG;
     hipStream_t s = rpg::as_stream(stream);
     const int quarters = (c + 63) / 64;                       // 64 output channels per workgroup
-    if ((d / 4 + quarters - 1) / quarters > NT) return RPG_ERR_BAD_ARG;      // one mbar column per thread
+    if ((d / 4 + quarters - 1) / quarters > AA_NT) return RPG_ERR_BAD_ARG;   // one mbar column per thread
     const int slot = rpg::timing_begin(RPG_TIMER_ATT_AGG, s);
-    hipLaunchKernelGGL(attention_aggregate_kernel, dim3(n, quarters), dim3(NT), (2 * c + 8 + 512) * sizeof(float), s, gtp,
+    hipLaunchKernelGGL(attention_aggregate_kernel, dim3(n, quarters), dim3(AA_NT), 0, s, gtp,
                        reinterpret_cast<const float4*>(msg), rowptr, perm, reinterpret_cast<const float4*>(bias), c, d / 4, ybar,
                        reinterpret_cast<float4*>(mbar));
     // algorithmic bytes: the scatter-mean of SURVEY 8(a) A9 (messages E*D*4 + targets E*8 + output N*D*4) plus the attention
