@@ -104,7 +104,7 @@ class _InputPipeline:
         import os
         from concurrent.futures import ThreadPoolExecutor
         # 8 threads reach the ~40 GB/s the host moves (memcpy for fp32 staging, rpg_host_f32_to_bf16 for bf16 staging)
-        self.workers = max(1, min(int(os.environ.get("RPG_STAGE_WORKERS", "0")) or (8 if dtype == torch.float32 else 16), (os.cpu_count() or 2) // 2))
+        self.workers = max(1, min(int(os.environ.get("RPG_STAGE_WORKERS", "0")) or (8 if dtype == torch.float32 else 16), max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2) // 2)))
         self.pool = ThreadPoolExecutor(max_workers=self.workers) if self.workers > 1 else None
         self.dev = [torch.empty((rows, row_floats), dtype=dtype, device=device) for _ in range(2)]
         self.sent = [torch.cuda.Event() for _ in range(2)]
@@ -206,8 +206,15 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
     at 256x341), nor the D2H of the poses, nor the numpy work of test.py:213-251 leaves the GPU idle.
     ``stats`` (optional dict) receives ``h2d_bytes`` (bytes sent through the staging pipeline) and ``micro_batches``.  ``bf16_input`` (default: whatever the model
     accepts, i.e. True for the bf16 encoder with its fused stem): host-resident images are rounded to bf16 while they are staged."""
-    from .shard import gather_rows, shard_counts, shard_range
+    from .shard import bind_rank_to_host_slice, gather_rows, shard_counts, shard_range
     pose_m, pose_s = np.asarray(pose_m, dtype=np.float64), np.asarray(pose_s, dtype=np.float64)
+    if world > 1 and torch.device(device).type == "cuda":
+        # one process per GPU on a shared host: this rank's staging threads and pinned buffers stay on its share of the
+        # cores / its GPU's NUMA node (shard.bind_rank_to_host_slice; RPG_BIND_RANKS=0 switches it off).  LOCAL_* from the
+        # launcher when it set them (ranks of other nodes do not share this host)
+        import os
+        bind_rank_to_host_slice(int(os.environ.get("LOCAL_RANK", rank)), int(os.environ.get("LOCAL_WORLD_SIZE", world)),
+                                torch.device(device).index)
     lo, hi = shard_range(len(graphs), rank, world)
     on_gpu = torch.device(device).type == "cuda"
     preds: List[np.ndarray] = []
@@ -303,9 +310,12 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
         stats["micro_batches"] = n_batches
     pred = np.stack(preds) if preds else np.zeros((0, 7))
     targ = np.stack(targs) if targs else np.zeros((0, 7))
-    if world > 1:
+    import torch.distributed as dist
+    if world > 1 or (dist.is_available() and dist.is_initialized() and dist.get_world_size() == world):
+        # under a process group the collective runs at ANY world size, 1 included: a one-GPU box then executes the same RCCL
+        # all-gather the 4- / 8-GPU stream does (tools/eval_stream.py under torch.distributed.run)
         both = torch.from_numpy(np.concatenate([pred, targ], 1)).to(device)
-        both = gather_rows(both, shard_counts(len(graphs), world)).cpu().numpy()
+        both = gather_rows(both, shard_counts(len(graphs), world), always=True).cpu().numpy()
         pred, targ = both[:, :7], both[:, 7:]
     return errors(pred, targ)
 

@@ -9,7 +9,8 @@ latency-bound on xGMI, no bucketing needed.
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+import os
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -47,3 +48,84 @@ def gather_rows(local: torch.Tensor, counts: List[int], group=None, always: bool
     if all(c == m for c in counts):
         return out
     return torch.cat([out[r * m: r * m + c] for r, c in enumerate(counts)], 0)
+
+
+# ---- host placement of a rank (round 5) -------------------------------------------------------------------------------
+# The reference is one process (testing/test.py:78-80,192-194); eight ranks on a two-socket GPU host are eight processes whose
+# staging threads (evaluate._InputPipeline: 8-16 per rank) and pinned buffers would otherwise float over both sockets: a
+# rank's pageable -> pinned copy and the DMA out of the pinned buffer then cross the socket link for half of the ranks.
+
+_BOUND = None        # ((local_rank, local_world), cpus) once bind_rank_to_host_slice has narrowed this process's mask
+
+
+def _parse_cpulist(text: str) -> List[int]:
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_local_cpus(device_index: int) -> Optional[List[int]]:
+    """CPUs of the NUMA node GPU ``device_index`` hangs off, from sysfs (PCI address -> local_cpulist), or None if the
+    platform does not say (no sysfs entry, numa_node = -1, virtualised PCI topology).  Never touches the GPU runtime beyond
+    the cached device properties."""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        dom, bus, devn = getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", None), getattr(p, "pci_device_id", None)
+        if bus is None or devn is None:
+            return None
+        base = f"/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{devn:02x}.0"
+        with open(os.path.join(base, "numa_node")) as f:
+            if int(f.read().strip()) < 0:
+                return None
+        with open(os.path.join(base, "local_cpulist")) as f:
+            cpus = _parse_cpulist(f.read())
+        return cpus or None
+    except Exception:
+        return None
+
+
+def rank_cpu_slice(local_rank: int, local_world: int, cpus: Optional[Sequence[int]] = None) -> List[int]:
+    """The contiguous slice of ``cpus`` (default: this process's current affinity mask, in ascending order) that
+    ``local_rank`` of ``local_world`` ranks on this host gets: equal shares, every CPU in exactly one share.  On a
+    two-socket host with the usual socket-major CPU numbering ranks 0..W/2-1 land on socket 0 and the rest on socket 1,
+    like the GPUs they drive."""
+    cpus = sorted(cpus if cpus is not None else os.sched_getaffinity(0))
+    if local_world <= 1 or not cpus:
+        return list(cpus)
+    lo, hi = shard_range(len(cpus), local_rank, local_world)
+    return list(cpus[lo:hi]) if hi > lo else [cpus[local_rank % len(cpus)]]
+
+
+def bind_rank_to_host_slice(local_rank: int, local_world: int, device_index: Optional[int] = None) -> Optional[List[int]]:
+    """Pin the calling process (and every thread it starts afterwards: staging pools inherit the mask; pinned buffers
+    allocated afterwards are first touched from these CPUs) to its share of the host: the CPUs of its GPU's NUMA node
+    where sysfs names them -- cut among the ranks whose GPUs share that node -- else an equal contiguous slice of the
+    current mask.  Returns the CPU list, or None if nothing was changed (single rank, RPG_BIND_RANKS=0, unsupported
+    platform).  Plain ``os.sched_setaffinity``: no exec, no numactl hop (safe after the GPU has been initialised)."""
+    global _BOUND
+    if local_world <= 1 or os.environ.get("RPG_BIND_RANKS", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    if _BOUND is not None:                 # once per process: a second call would cut the already narrowed mask again
+        return _BOUND[1] if _BOUND[0] == (local_rank, local_world) else None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        cpus = None
+        near = gpu_local_cpus(local_rank if device_index is None else device_index)
+        if near:
+            near = [c for c in near if c in set(allowed)]
+            # ranks are assumed spread evenly over the NUMA nodes (GPUs 0..W/2-1 on node 0 ...): this node's share of the ranks
+            nodes = max(1, round(len(allowed) / max(1, len(near))))
+            per_node = max(1, local_world // nodes)
+            if near:
+                cpus = rank_cpu_slice(local_rank % per_node, per_node, near)
+        if not cpus:
+            cpus = rank_cpu_slice(local_rank, local_world, allowed)
+        os.sched_setaffinity(0, cpus)
+        _BOUND = ((local_rank, local_world), cpus)
+        return cpus
+    except Exception:
+        return None

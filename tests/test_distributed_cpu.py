@@ -132,3 +132,35 @@ def test_bench_spawns_its_own_ranks(tmp_path, capsys, world):
     assert rc == 0 and len(out) == 1                        # exactly ONE line on stdout: the JSON
     line = json.loads(out[0])
     assert line["n_gpus"] == world and line["value"] == world * (world + 1) / 2 and line["argv"] == ["--gpus", str(world), "--steps", "3"]
+
+
+def _bind_child(q, local_rank, local_world):
+    from relpose_gnn_amd import shard
+    before = sorted(os.sched_getaffinity(0))
+    got = shard.bind_rank_to_host_slice(local_rank, local_world)
+    again = shard.bind_rank_to_host_slice(local_rank, local_world)       # idempotent: the narrowed mask is not cut again
+    q.put((before, got, again, sorted(os.sched_getaffinity(0))))
+
+
+def test_rank_host_slices_partition_the_cpus():
+    """Host placement of the ranks (round 5): equal contiguous CPU slices, every CPU in exactly one; the sysfs cpulist parser;
+    and -- in a child process, so that pytest keeps its own mask -- bind_rank_to_host_slice narrows the affinity once."""
+    from relpose_gnn_amd import shard
+    assert shard._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    cpus = list(range(128))
+    for w in (1, 2, 4, 8):
+        parts = [shard.rank_cpu_slice(r, w, cpus) for r in range(w)]
+        assert sorted(c for p in parts for c in p) == cpus and max(map(len, parts)) - min(map(len, parts)) <= 1
+        if w == 8:
+            assert all(max(p) < 64 for p in parts[:4]) and all(min(p) >= 64 for p in parts[4:])     # socket-major numbering
+    assert shard.rank_cpu_slice(5, 8, [0, 1, 2]) == [2]                  # more ranks than CPUs: still one CPU each
+    if not hasattr(os, "sched_setaffinity") or len(os.sched_getaffinity(0)) < 2:
+        pytest.skip("no affinity control here")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_bind_child, args=(q, 1, 2))
+    p.start()
+    before, got, again, after = q.get(timeout=120)
+    p.join(30)
+    assert got == before[len(before) // 2 + len(before) % 2:] or got == shard.rank_cpu_slice(1, 2, before)
+    assert again == got and after == got and sorted(os.sched_getaffinity(0)) == before

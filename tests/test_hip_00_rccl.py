@@ -69,3 +69,17 @@ def test_bench_through_its_own_launcher_world1():
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["process_group"].startswith("nccl (RCCL), world_size=1")
+
+
+def test_eval_stream_tool_under_its_launcher_world1():
+    """tools/eval_stream.py (the configs[3] / [4] multi-rank driver) under its own ``torch.distributed.run`` command line at
+    world size 1: rank 0 initialises RCCL, evaluate_stream shards the stream (one block), the [G, 14] pose rows go through the
+    real all_gather_into_tensor, then barrier + all_reduce(MAX) of the elapsed time."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "eval_stream.py"), "--graphs", "24", "--shape", "64x96",
+           "--micro-batch", "8", "--pool", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=_env(), cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{") and '"graphs_per_s"' in ln]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["rccl_ranks_seen"] == 1 and rec["graphs"] == 24 and rec["graphs_per_s"] > 0

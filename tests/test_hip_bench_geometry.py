@@ -313,8 +313,12 @@ def test_fp32_error_is_the_fp32_noise_floor(dev, shape):
     """the fp32 forward sits 1.2e-5 (configs[1]) / 6.7e-5 (256x341, abs poses) from the CPU fp32 oracle
     against a 1e-4 bar -- is that kernel error or the conditioning of the randomly initialised network?  Three seeds per
     shape; the float64 run of the same oracle is the exact answer.  Asserted: next to the 1e-4 bar vs the fp32 oracle, the
-    HIP result is no further from the EXACT answer than twice the CPU fp32 reference itself is (the reference's own fp32
-    rounding noise, amplified ~100x by the random abs-pose head, is the floor; a kernel bug would break the ratio)."""
+    HIP result is no further from the EXACT answer than 1.5 x the CPU fp32 reference itself is (the reference's own fp32
+    rounding noise, amplified ~100x by the random abs-pose head, is the floor; a kernel bug would break the ratio).
+    Round 5 (two-level accumulation in the fp32 Linears, RPG_TUNE_FOLD_K): the bar was 2.0 through round 4; measured ratios
+    now 0.75 .. 1.21 on the abs poses and 0.84 .. 1.61 on the rel poses, the 1.61 being 3.2e-6 against 2.0e-6 -- two-graph
+    maxima at a few ulp of the output, hence the floor of 3e-6 under the ratio (the fixed-pair test at 64 graphs x 256x341,
+    tests/test_hip_eval_geometry.py, asserts 1.2 on numbers ten times larger)."""
     h, w, G = (224, 224, 2) if shape == "configs1_224" else (256, 341, 2)
     m, sd = _r3_model(dev, img_h=h)
     from relpose_gnn_amd.graph import fc_batch
@@ -331,6 +335,6 @@ def test_fp32_error_is_the_fp32_noise_floor(dev, shape):
         _report(rec)
         assert rec["hip_vs_fp32_oracle_abs"] < 1e-4 and rec["hip_vs_fp32_oracle_rel"] < 1e-4, rec
         for k in ("abs", "rel"):
-            # floor of 2e-6: where the CPU reference happens to land within rounding of the exact answer the ratio is noise
-            assert rec[f"hip_vs_fp64_{k}"] <= 2.0 * max(rec[f"cpu_fp32_vs_fp64_{k}"], 2e-6), rec
+            # floor of 3e-6: where the CPU reference happens to land within rounding of the exact answer the ratio is noise
+            assert rec[f"hip_vs_fp64_{k}"] <= 1.5 * max(rec[f"cpu_fp32_vs_fp64_{k}"], 3e-6), rec
         worst[seed] = rec

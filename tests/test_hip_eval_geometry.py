@@ -113,16 +113,16 @@ def _vs_exact(stream, a_hip, graphs):
 def test_configs3_fp32_micro_batch_as_streamed_vs_oracle(dev, stream):
     """configs[3]: fp32, 64 graphs x 8 x 256x341 on two streams (and on one), all 64 graphs against the CPU oracle.
 
-    Bars: encoder features and relative poses <= 1e-4 batch-wide AND per graph (measured r4: 7e-7 and 7e-6; the relative
-    poses are what the caller consumes, testing/test.py:227-232).
-    Absolute poses: 1.5e-4, with the reason measured here rather than assumed.  With iid-noise pixels the eight 256x341
-    images of a graph pool to nearly the same feature vector, and the randomly initialised GNN + abs head turn fp32 rounding
-    noise into ~1e-4 of max|abs|: the HIP GNN and the oracle's GNN fed the SAME features differ by 7.6e-5 (the bf16 test
-    below measures it), the CPU fp32 reference itself sits 4.5e-5 from the exact float64 answer, and the maximum over 512
-    nodes x 6 of the distance between the two fp32 evaluations lands at 0.90e-4 (two streams) / 1.02e-4 (one stream).
-    Hence, next to the 1.5e-4 bound: on a FIXED pair of graphs (no selection) HIP must be no further from the float64 answer
-    than twice the CPU fp32 reference is (the rule of test_fp32_error_is_the_fp32_noise_floor: measured 7.3e-5 vs 4.5e-5),
-    and on the two graphs where HIP and the CPU oracle differ most HIP stays within 1.5e-4 of the float64 answer (1.2e-4)."""
+    Bars: encoder features, relative AND absolute poses <= 1e-4 of the CPU fp32 oracle, batch-wide (features / relative poses also
+    per graph) -- the north-star bar, un-moved (round 4 had 1.5e-4 on the absolute poses here: 0.90e-4 / 1.02e-4 measured).
+    With iid-noise pixels the eight 256x341 images of a graph pool to nearly the same feature vector, and the randomly
+    initialised GNN + abs head turn fp32 rounding noise into several 1e-5 of max|abs|; the CPU fp32 reference itself sits
+    4.5e-5 from the exact float64 answer.  Round 5 cut the HIP side's share: the fp32 Linears accumulate in two levels
+    (RPG_TUNE_FOLD_K = 256: the v_mfma_f32_32x32x2_f32 chain is folded into a second accumulator every 256 of K, like a
+    blocked CPU sum) -- measured 5.7e-5 (two streams) / 6.8e-5 (one stream) against the fp32 oracle, and against float64
+    4.3e-5 / 4.1e-5 on the fixed pair of graphs 0, 1 where the CPU fp32 reference is 4.5e-5 away (ratio 0.96 / 0.90; round 4:
+    7.3e-5, ratio 1.6).  Asserted: HIP no further from float64 than 1.2 x the CPU fp32 reference on that fixed pair (no
+    selection), and within 1e-4 of float64 on the two graphs where HIP and the CPU oracle differ most."""
     m = stream["model"]
     m.encoder_dtype, m.gnn_dtype, m.hip_streams = "f32", "f32", 2
     batch = _micro_batch(stream, dev)
@@ -149,8 +149,8 @@ def test_configs3_fp32_micro_batch_as_streamed_vs_oracle(dev, stream):
                  "worst_abs_graphs": worst, "hip_vs_fp64_abs_on_worst": hip_w, "cpu_fp32_vs_fp64_abs_on_worst": cpu_w,
                  "hip_vs_fp64_abs_graphs_0_1": hip_f, "cpu_fp32_vs_fp64_abs_graphs_0_1": cpu_f})
         assert er < 1e-4 and ef < 1e-4 and pg_r < 1e-4 and pg_f < 1e-4, (streams, er, ef, pg_r, pg_f)
-        assert ea < 1.5e-4 and hip_w < 1.5e-4, (streams, ea, hip_w, cpu_w)
-        assert hip_f <= 2.0 * max(cpu_f, 2e-6), (streams, hip_f, cpu_f)
+        assert ea < 1e-4 and hip_w < 1e-4, (streams, ea, hip_w, cpu_w)
+        assert hip_f <= 1.2 * max(cpu_f, 2e-6), (streams, hip_f, cpu_f)
 
 
 @pytest.mark.parametrize("gnn_dtype", ["f32", "bf16"])
@@ -161,8 +161,8 @@ def test_configs4_bf16_micro_batch_as_streamed_vs_oracle(dev, stream, gnn_dtype)
     What the bf16 kernels control is stated separately from what the randomly initialised network does with it:
       (1) encoder: features vs the oracle's <= 1e-2 max-norm, batch-wide and per graph (36 bf16 layers x ~1e-3, random walk);
       (2) GNN kernels: HIP poses vs the ORACLE'S GNN RUN ON THE HIP FEATURES (same input, so this is the GNN's own error):
-          fp32 GNN <= 1e-4 (rel; measured 7.5e-6) / 1.5e-4 (abs: the fp32 noise floor of the abs head at this shape, see the
-          fp32 test; measured 7.6e-5); bf16 GNN Linears (~20 chained bf16-input GEMMs) <= 2e-2 relative L2 and <= 6e-2
+          fp32 GNN <= 1e-4 on both (rel: measured 3.7e-6; abs: 6.6e-5 -- the fp32 noise floor of the abs head at this shape,
+          see the fp32 test; round 4, before the two-level accumulation: 7.5e-6 / 7.6e-5 under a 1.5e-4 bar); bf16 GNN Linears (~20 chained bf16-input GEMMs) <= 2e-2 relative L2 and <= 6e-2
           max-norm on the rel poses (measured r4: 1.47e-2 / 4.2e-2 -- the max-norm is the 224x224 bar 1.5 x 2e-2 times the
           ratio of the conditioning of the two shapes, 5.8x against 4x);
       (3) end to end vs the full fp32 oracle: the relative-L2 bars of test_configs2_bf16_forward_as_benched_vs_oracle
@@ -213,7 +213,7 @@ def test_configs4_bf16_micro_batch_as_streamed_vs_oracle(dev, stream, gnn_dtype)
              "abs_pose_rel_err": ea, "rel_pose_rel_err": er, "worst_graph_rel_pose_rel_err": pg_r, "l2_abs": l2a, "l2_rel": l2r})
     assert ef < BF16_FEAT and pg_f < BF16_FEAT and l2f < BF16_FEAT, (ef, pg_f, l2f)
     if gnn_dtype == "f32":
-        assert gnn_r < 1e-4 and gnn_a < 1.5e-4, (gnn_r, gnn_a)
+        assert gnn_r < 1e-4 and gnn_a < 1e-4, (gnn_r, gnn_a)
     else:
         assert gnn_l2r < 2e-2 and gnn_r < 6e-2, (gnn_l2r, gnn_r)
     k = 1.0 if gnn_dtype == "f32" else 1.5

@@ -589,3 +589,154 @@ def test_graph_replay_equals_eager(dev):
     assert torch.equal(a, e2[0]) and torch.equal(r, e2[1])
     with pytest.raises(ValueError):
         runner(_data(S.synth_images(8 * 4, 32, 40, seed=33), 8, dev))
+
+
+def test_knn_graph_per_stream_slot_equals_single_stream(dev):
+    """Round 5: with ``knn > 0`` (the reference's default CLI, testing/test.py:308) the batch still runs on several streams: every
+    slot builds the kNN graph of ITS graphs from its own encoder output (posenet.py:1047-1048).  1 / 2 / 3 streams return the same
+    edge list (bit-exact, whole-batch node ids, batch order) and the same poses; graph sizes 8, 4, 8, 8, 4, 8, 8 with k = 3."""
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd.graph import Batch, Data, fc_edge_index
+    m, _ = _build(64, 32, (8, 16, 32, 64), (1, 1, 1, 1), dev)
+    sizes = [8, 4, 8, 8, 4, 8, 8]
+    graphs = [Data(x=S.synth_images(n, 32, 40, seed=300 + i), edge_index=fc_edge_index(n)) for i, n in enumerate(sizes)]
+    b = Batch.from_data_list(graphs).to(dev)
+    m.knn = 3
+    outs = []
+    try:
+        for streams in (1, 2, 3):
+            m.hip_streams = streams
+            a, r, ei = m(b)
+            m.check_edge_index()
+            assert ei.shape == (2, 3 * sum(sizes)) and r.shape == (3 * sum(sizes), 6)
+            outs.append((a.cpu(), r.cpu(), ei.cpu()))
+        # an explicit k keeps the single-stream path (posenet.py:1043-1046,1088-1089) and agrees with it
+        a_k, r_k, ei_k = m(b, k=3)
+        assert torch.equal(ei_k.cpu(), outs[0][2])
+    finally:
+        m.knn, m.hip_streams = -1, 2
+    for a, r, ei in outs[1:]:
+        assert torch.equal(ei, outs[0][2])
+        assert rel_err(a, outs[0][0]) < 1e-5 and rel_err(r, outs[0][1]) < 1e-5
+    # every edge stays inside its graph and points at its query node (row 1), k neighbours each, in node order
+    first = np.concatenate([[0], np.cumsum(sizes)])
+    e = outs[0][2].numpy()
+    assert (np.searchsorted(first, e[0], side="right") == np.searchsorted(first, e[1], side="right")).all()
+    assert np.array_equal(e[1], np.repeat(np.arange(sum(sizes)), 3))
+
+
+def test_dropout_on_the_multi_stream_path_with_seeded_masks(dev):
+    """Round 5: ``droprate > 0`` (test.py:309 defaults to 0.5) keeps the multi-stream schedule; dropout + heads run per stream
+    slot (posenet.py:1073-1086).  With the generator re-seeded the masks are reproduced in the order the slots draw them --
+    (nodes, edges) of slot 0, then of slot 1 -- and the oracle's heads on the identically masked features equal the outputs."""
+    import relpose_gnn_amd.synth as S
+    from oracle import posenet_ref as O
+    m, sd = _build(64, 32, (8, 16, 32, 64), (1, 1, 1, 1), dev, droprate=0.5)
+    m.hip_streams = 2
+    x = S.synth_images(40, 32, 40, seed=31)                  # 5 graphs: slots of 2 and 3 graphs
+    d = _data(x, 8, dev)
+    parts = m._partition(d, 40, 5 * 56)
+    assert [(p[0], p[1]) for p in parts] == [(0, 16), (16, 40)]
+    torch.cuda.manual_seed(77)
+    a, r, _ = m(d)
+    torch.cuda.synchronize()
+    torch.cuda.manual_seed(77)
+    mn, me = [], []
+    for n0, n1, e0, e1, _ in parts:
+        mn.append(torch.nn.functional.dropout(torch.ones(n1 - n0, 64, device=dev), p=0.5))
+        me.append(torch.nn.functional.dropout(torch.ones(e1 - e0, 64, device=dev), p=0.5))
+    oa, orr, _ = O.posenet_forward(sd, x, d.edge_index.cpu(), 32, 2, node_mask=torch.cat(mn).cpu(), edge_mask=torch.cat(me).cpu())
+    ea, er = rel_err(a.cpu(), oa), rel_err(r.cpu(), orr)
+    _report("dropout_seeded_masks_two_stream_slots", ea, er)
+    assert ea < TOL and er < TOL, (ea, er)
+
+
+def test_reference_eval_loop_as_written_batch_size_1(dev):
+    """The 3-line drop-in of INTEGRATION.md exercised as the reference's caller is written (testing/test.py:205-251): one graph
+    per iteration, ``model(data.to(device))``, ``output.size()``, ``output_R.cpu().data.numpy().reshape((-1, s[-1]))``,
+    ``len(data)``, ``edge_index.cpu().data.numpy()``, first edge into node 0, target[src] - rel, qexp, un-normalisation --
+    against ``evaluate_stream`` (micro-batched, same module) and the oracle forward + oracle post-processing."""
+    import relpose_gnn_amd.synth as S
+    from oracle import posenet_ref as O
+    from relpose_gnn_amd import evaluate as E
+    from relpose_gnn_amd.graph import Batch, Data, fc_edge_index
+    m, sd = _build(64, 32, (8, 16, 32, 64), (1, 1, 1, 1), dev)
+    pose_m, pose_s = np.array([0.5, -1.0, 2.0]), np.array([2.0, 3.0, 0.5])
+    graphs = [Data(x=S.synth_images(8, 32, 40, seed=500 + i), edge_index=fc_edge_index(8), y=S.hash_normal(f"lit.y{i}", (8, 6), 0.3),
+                   edge_attr=None) for i in range(5)]
+    pred_poses, targ_poses, batch_size, ref_node = [], [], 1, 0
+    for batch_idx, g in enumerate(graphs):
+        data = Batch.from_data_list([g])                     # DataLoader(batch_size=1) collation (test.py:192-194)
+        batch_size_ = min(len(data), batch_size)
+        output, output_R, edge_index = m(data.to(dev))
+        s = output.size()
+        output_R = output_R.cpu().data.numpy().reshape((-1, s[-1]))
+        target = data.y.to("cpu").numpy().reshape((-1, s[-1]))
+        edges = edge_index.cpu().data.numpy()
+        ref_idx = np.argwhere(edges[1] == 0)[ref_node, 0]
+        out = np.expand_dims(target[edges[0, ref_idx], :] - output_R[ref_idx, :], axis=0)
+        out = np.hstack((out[:, :3], np.asarray(tuple(E.qexp(p[3:]) for p in out))))
+        target = np.hstack((target[:, :3], np.asarray(tuple(E.qexp(p[3:]) for p in target))))
+        out[:, :3] = out[:, :3] * pose_s + pose_m
+        target[:, :3] = target[:, :3] * pose_s + pose_m
+        for j in range(batch_size_):
+            pred_poses.append(out[0])
+            targ_poses.append(target[0])
+            assert len(pred_poses) == batch_idx * batch_size + j + 1
+    pred_poses, targ_poses = np.array(pred_poses), np.array(targ_poses)
+    res = E.evaluate_stream(m, graphs, dev, micro_batch=4, pose_m=pose_m, pose_s=pose_s)
+    assert np.allclose(pred_poses, res.pred_poses, atol=2e-5) and np.allclose(targ_poses, res.targ_poses, atol=1e-6)
+    want = []
+    for g in graphs:
+        _, rel, _ = O.posenet_forward(sd, g.x, fc_edge_index(8), 32, 2)
+        raw = O.query_pose_from_relative(rel.numpy().astype(np.float64), g.y.numpy().astype(np.float64), fc_edge_index(8).numpy())
+        want.append(np.hstack((raw[:3] * pose_s + pose_m, O.qexp(raw[3:]))))
+    assert np.allclose(pred_poses, np.stack(want), atol=2e-4, rtol=1e-4)
+
+
+def test_foreign_torchvision_style_feature_extractor(dev):
+    """any module with torchvision's ResNet attribute layout works as ``feature_extractor`` -- only its
+    ``state_dict()`` (torchvision's key names), ``.avgpool`` and ``.fc.in_features`` are read (posenet.py:942-945).  Here a
+    plain nn.Module tree that is NOT relpose_gnn_amd.resnet.ResNet (torchvision itself is absent from this image): the
+    constructor replaces its avgpool / fc like the reference does, and the forward equals the package's own ResNet's."""
+    import torch.nn as nn
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd.posenet import PoseNetX_R2
+
+    class Block(nn.Module):                                  # torchvision.models.resnet.BasicBlock's attribute names
+        def __init__(self, cin, c, stride):
+            super().__init__()
+            self.conv1, self.bn1 = nn.Conv2d(cin, c, 3, stride, 1, bias=False), nn.BatchNorm2d(c)
+            self.conv2, self.bn2 = nn.Conv2d(c, c, 3, 1, 1, bias=False), nn.BatchNorm2d(c)
+            self.downsample = None
+            if stride != 1 or cin != c:
+                self.downsample = nn.Sequential(nn.Conv2d(cin, c, 1, stride, bias=False), nn.BatchNorm2d(c))
+
+    class Foreign(nn.Module):
+        def __init__(self, planes, blocks):
+            super().__init__()
+            self.conv1, self.bn1 = nn.Conv2d(3, planes[0], 7, 2, 3, bias=False), nn.BatchNorm2d(planes[0])
+            self.relu, self.maxpool = nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1)
+            cin = planes[0]
+            for li, (c, nb) in enumerate(zip(planes, blocks), start=1):
+                layer = []
+                for b in range(nb):
+                    layer.append(Block(cin, c, 2 if (li > 1 and b == 0) else 1))
+                    cin = c
+                setattr(self, f"layer{li}", nn.Sequential(*layer))
+            self.avgpool, self.fc = nn.AdaptiveAvgPool2d((1, 1)), nn.Linear(planes[-1], 1000)
+
+    planes, blocks, D = (8, 16, 32, 64), (1, 2, 1, 1), 64
+    sd = S.synth_state_dict(S.posenet_r2_param_shapes(D, D, D, planes, blocks), seed=5)
+    outs = []
+    from relpose_gnn_amd.resnet import ResNet
+    for fe in (Foreign(planes, blocks), ResNet(blocks, planes)):
+        m = PoseNetX_R2(fe, droprate=0.0, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D, input_img_height=32,
+                        use_gnn=True, knn=-1, use_AP=True, gnn_recursion=2)
+        assert not isinstance(m.feature_extractor, ResNet) or fe.__class__ is ResNet
+        assert m.feature_extractor.fc.out_features == D
+        m.load_state_dict(sd)                                 # torchvision key names: strict load
+        m = m.to(dev).eval()
+        a, r, _ = m(_data(S.synth_images(16, 32, 40, seed=6), 8, dev))
+        outs.append((a.cpu(), r.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

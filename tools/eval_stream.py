@@ -48,7 +48,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    # under a launcher (torchrun environment) the process group is RCCL at ANY world size, 1 included: a one-GPU box then runs
+    # the same all-gather / barrier / all_reduce the 4- and 8-GPU streams run (tests/test_hip_00_rccl.py)
+    under_launcher = "WORLD_SIZE" in os.environ
+    if under_launcher:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     import relpose_gnn_amd.synth as S
     from relpose_gnn_amd import evaluate as E
@@ -86,17 +90,17 @@ def main():
 
     bfin = None if args.h2d == "auto" else args.h2d == "bf16"
     E.evaluate_stream(model, graphs[: min(2 * mb, len(graphs))], dev, micro_batch=mb, bf16_input=bfin)      # warm-up (packing, workspaces, staging buffers)
-    if world > 1:
+    if under_launcher:
         dist.barrier()
     torch.cuda.synchronize()
     stats = {}
     t0 = time.perf_counter()
     res = E.evaluate_stream(model, graphs, dev, micro_batch=mb, rank=rank, world=world, stats=stats, bf16_input=bfin)   # THE product loop
     torch.cuda.synchronize()
-    if world > 1:
+    if under_launcher:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if under_launcher:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -107,10 +111,11 @@ def main():
                                       f"node images {args.input} ({'pinned double-buffered H2D on a copy stream' if args.input != 'resident' else 'no H2D'}"
                                       f"{', staged as bf16' if args.input != 'resident' and (bfin if bfin is not None else model.accepts_bf16_input) else ''}), "
                                       "D2H + test.py post-processing per graph included",
-                          "input": args.input, "n_gpus": world, "graphs": args.graphs, "seconds": round(dt, 3),
+                          "input": args.input, "n_gpus": world, "rccl_ranks_seen": dist.get_world_size() if under_launcher else None,
+                          "cpu_affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "graphs": args.graphs, "seconds": round(dt, 3),
                           "graphs_per_s": round(args.graphs / dt, 1),
                           "h2d_gb_per_s": round(stats.get("h2d_bytes", 0) / dt / 1e9, 2)}), flush=True)
-    if world > 1:
+    if under_launcher:
         dist.destroy_process_group()
 
 
