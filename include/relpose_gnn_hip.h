@@ -247,6 +247,16 @@ int rpg_gnn_forward_bf16(const float* const* tensors, int n_tensors, const void*
                          int gnn_recursion, float* abs_pose, float* rel_pose, float* node_out, float* edge_out,
                          int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
+/* One 64-channel identity BasicBlock of the bf16 encoder as a single kernel (round 5): y = relu(bn2(conv2(relu(bn1(conv1(x))))) + x),
+ * both convolutions 3x3 / stride 1 / pad 1, 64 -> 64 channels, x / y bf16 NHWC [n][h][w][64] (y must not alias x), weights bf16
+ * [64][3][3][64] (OHWI), folded BatchNorm scale / shift fp32 [64] (16-byte aligned).  Replaces the two aten conv2d + batch_norm +
+ * relu (+ add) sequences of torchvision's BasicBlock.forward (reference call site: modules/posenet.py:1037) for ResNet34's
+ * layer 1.  The intermediate activation is rounded to bf16 exactly where the two-launch path stores it: outputs are bit-identical
+ * to rpg_conv2d_bn_act_nhwc_bf16 called twice.  Maps up to 63 pixels wide; RPG_ERR_BAD_ARG for shapes it does not take (the
+ * caller then uses two convolution calls).  No workspace, no allocation, no synchronisation. */
+int rpg_basicblock64_bf16(const void* x, const void* w1_ohwi, const float* scale1, const float* shift1, const void* w2_ohwi,
+                          const float* scale2, const float* shift2, void* y, int n, int h, int w, void* stream);
+
 /* Building blocks of the above.  rpg_f32_to_bf16: dst[r][col_off + c] = bf16(src[r][c]) for c < cols (cols, col_off,
  * ld_dst % 8 == 0).  rpg_linear_bf16: out[m][n_out] (fp32) = act(a[m][k] (bf16) * weight[n_out][k]^T (bf16) + bias +
  * residual[(res_idx ? res_idx[r] : r) * ldr + :] + residual2[res2_idx[r] * ldr + :]); k % 8 == 0, n_out % 4 == 0.
@@ -347,6 +357,9 @@ int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
                                      accumulator is folded into a second one and restarted every `value` of K (a multiple of 64; default 256; 0 = one
                                      sequential chain over all of K as in rounds 1-4).  Summation order only: cuts the rounding noise of the K = 2048..4096
                                      GNN Linears (reference: addmm in my_gnn_layer.py:236-239,304-311 through oneDNN's blocked sums) */
+#define RPG_TUNE_BF16_FUSE_BLOCK 27  /* bf16 encoder: 1 (default) = 64-channel identity BasicBlocks (ResNet34 layer 1) run as ONE kernel, conv1 + BN + ReLU
+                                     + conv2 + BN + identity + ReLU with the intermediate activation in LDS (rpg_basicblock64_bf16; bit-identical
+                                     to the two convolution launches) | 0 = two launches */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -27,7 +27,7 @@ SYMBOLS = (
     "rpg_resnet_forward_bf16", "rpg_gnn_forward_bf16", "rpg_f32_to_bf16", "rpg_linear_bf16",
     "rpg_release_scratch", "rpg_timing_read_ex", "rpg_stem_conv7x7s2_bn_relu_maxpool_f32", "rpg_stem_pair_table",
     "rpg_attention_aggregate_f32", "rpg_stem_conv7x7s2_bn_relu_maxpool_bf16", "rpg_stem_conv7x7s2_bn_relu_maxpool_bf16_xbf16",
-    "rpg_resnet_forward_bf16_xbf16", "rpg_host_f32_to_bf16",
+    "rpg_resnet_forward_bf16_xbf16", "rpg_host_f32_to_bf16", "rpg_basicblock64_bf16",
 )
 
 
@@ -73,6 +73,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.rpg_timing_enable.argtypes = [_i]
     lib.rpg_set_tuning.argtypes = [_i, _i]
     lib.rpg_conv2d_bn_act_nhwc_bf16.argtypes = [_vp] * 6 + [_i] * 11 + [_vp]
+    lib.rpg_basicblock64_bf16.argtypes = [_vp] * 8 + [_i] * 3 + [_vp]
     lib.rpg_resnet_bf16_workspace_bytes.argtypes = [_i, _i, _i, C.POINTER(_i)]
     lib.rpg_resnet_bf16_workspace_bytes.restype = _sz
     lib.rpg_resnet_forward_bf16.argtypes = [C.POINTER(_vp), _i, C.POINTER(_i), C.POINTER(_i), _i, _vp, _i, _i, _i, _vp,

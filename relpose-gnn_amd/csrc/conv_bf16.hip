@@ -174,7 +174,7 @@ __device__ __forceinline__ void bf16_tile_epilogue_lean_body(f32x16 (&acc)[FM][F
     const unsigned row_b = 2u * (unsigned)ep.ldc;             // bytes per output row
     const unsigned base = n_ok ? (unsigned)r_in * row_b + 2u * (unsigned)nb : OOB;      // row r_in of fragment 0
     const int rows_left = M - mw;                             // rows of this wave's range that exist (may be <= 0)
-    const float floor_v = ep.relu ? 0.f : -INFINITY;
+    const bool relu = ep.relu != 0;          // (a select, not a max with -inf: a NaN accumulator of a non-ReLU convolution stays NaN, as in the general epilogue)
     auto off = [&](int i, int t) -> unsigned {
         const int r = i * 32 + r_in + RPI * t;
         return (n_ok && r < rows_left) ? base + (unsigned)(i * 32 + RPI * t) * row_b : OOB;
@@ -204,7 +204,8 @@ __device__ __forceinline__ void bf16_tile_epilogue_lean_body(f32x16 (&acc)[FM][F
                 const bf16x4 rs = __builtin_bit_cast(bf16x4, rs_cur[t]);
                 y.x += (float)rs[0]; y.y += (float)rs[1]; y.z += (float)rs[2]; y.w += (float)rs[3];
             }
-            const bf16x4 ob = {(__bf16)fmaxf(y.x, floor_v), (__bf16)fmaxf(y.y, floor_v), (__bf16)fmaxf(y.z, floor_v), (__bf16)fmaxf(y.w, floor_v)};
+            const bf16x4 ob = {(__bf16)(relu ? fmaxf(y.x, 0.f) : y.x), (__bf16)(relu ? fmaxf(y.y, 0.f) : y.y), (__bf16)(relu ? fmaxf(y.z, 0.f) : y.z),
+                               (__bf16)(relu ? fmaxf(y.w, 0.f) : y.w)};
 #if defined(RPG_PATCH_ABL) && (RPG_PATCH_ABL & 4)      // diagnostic: all stores of the wave land in one 64-KB window (L2-resident): the
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2e, ob), ro, off(i, t) & 0xffffu, 0, 0);      // epilogue without its HBM writes
 #else
@@ -1269,6 +1270,8 @@ bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, c
     return true;
 }
 
+#include "block_bf16.inc"
+
 #ifdef RPG_PROBE_WS64
 // the weights-stationary layer-1 experiment of round 3 (correct, not faster): lives in tools/probes/, compiled in on request only
 #include "../../tools/probes/conv3x3_bf16_ws64.inc"
@@ -1384,6 +1387,7 @@ void bf16_set_patch(int v) { g_bf16_stages = v >= 10 ? 3 : 4; g_bf16_patch = v %
 void bf16_set_fused_stem(int on) { g_bf16_fused_stem = on; }
 void bf16_set_lean_epi(int on) { g_bf16_lean_epi = on; }
 void bf16_set_persist(int v) { g_bf16_persist = v; }
+void bf16_set_fuse_block(int v) { g_bf16_fuse_block = v; }
 void bf16_set_linear_dma(int v) { g_bf16_linear_dma = v; }
 void bf16_set_chunk(int images, int min_mb) { g_bf16_chunk = images; g_bf16_chunk_mb = min_mb; }
 #ifdef RPG_PROBE_WS64
@@ -1704,6 +1708,20 @@ static int resnet_forward_bf16_impl(const void* const* tensors, int n_tensors, c
             void* T = buf[(cur + 1) & 3];
             void* Y = buf[(cur + 2) & 3];
             void* D = buf[(cur + 3) & 3];
+            // 64-channel identity block (layer 1): conv1 + BN + ReLU + conv2 + BN + identity + ReLU in one kernel, the intermediate
+            // on chip (block_bf16.inc; bit-identical to the two launches below)
+            if (!ds && c == 64 && g_bf16_fuse_block && (long)n * hh * ww >= 8192) {
+                const int slot = rpg::timing_begin(RPG_TIMER_CONV, s);
+                if (launch_block64_fused(X, tensors[ti], (const float*)tensors[ti + 1], (const float*)tensors[ti + 2], tensors[ti + 3],
+                                         (const float*)tensors[ti + 4], (const float*)tensors[ti + 5], Y, n, hh, ww, s)) {
+                    rpg::timing_end(slot, 2.0 * 2.0 * (double)n * hh * ww * 64.0 * 9.0 * 64.0, s);
+                    RPG_CHECK_LAUNCH("basicblock64_bf16");
+                    ti += 6;
+                    cur = (cur + 2) & 3;
+                    continue;
+                }
+                rpg::timing_end(slot, 0.0, s);
+            }
             if ((rc = rpg::launch_conv_bf16(X, tensors[ti], (const float*)tensors[ti + 1], (const float*)tensors[ti + 2],
                                             nullptr, T, n, hh, ww, cin, c, 3, 3, stride, 1, 1, 0, s)) != RPG_OK)
                 return rc;
@@ -1747,6 +1765,14 @@ extern "C" int rpg_resnet_forward_bf16_xbf16(const void* const* tensors, int n_t
                                              size_t workspace_bytes, void* stream) {
     return resnet_forward_bf16_impl(tensors, n_tensors, blocks, planes, feat_dim, x_nchw_bf16, 1, n, h, w, feat, workspace,
                                     workspace_bytes, stream);
+}
+
+extern "C" int rpg_basicblock64_bf16(const void* x, const void* w1_ohwi, const float* scale1, const float* shift1, const void* w2_ohwi,
+                                      const float* scale2, const float* shift2, void* y, int n, int h, int w, void* stream) {
+    if (!x || !y || x == y || !rpg::aligned16(x) || !rpg::aligned16(y) || !rpg::aligned16(w1_ohwi) || !rpg::aligned16(w2_ohwi)) return RPG_ERR_BAD_ARG;
+    if (!launch_block64_fused(x, w1_ohwi, scale1, shift1, w2_ohwi, scale2, shift2, y, n, h, w, rpg::as_stream(stream))) return RPG_ERR_BAD_ARG;
+    RPG_CHECK_LAUNCH("basicblock64_bf16");
+    return RPG_OK;
 }
 
 extern "C" int rpg_f32_to_bf16(const float* src, int ld_src, void* dst, int ld_dst, int col_off, long rows, int cols,

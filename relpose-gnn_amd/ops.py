@@ -123,6 +123,25 @@ def conv2d_bn_act_nhwc_bf16(x: torch.Tensor, w_ohwi: torch.Tensor, scale: Option
     return y
 
 
+def basicblock64_bf16(x: torch.Tensor, w1_ohwi: torch.Tensor, scale1: torch.Tensor, shift1: torch.Tensor, w2_ohwi: torch.Tensor,
+                      scale2: torch.Tensor, shift2: torch.Tensor) -> torch.Tensor:
+    """relu(bn2(conv2(relu(bn1(conv1(x))))) + x) for a 64-channel identity BasicBlock in ONE kernel (the intermediate stays in
+    LDS): x bf16 NHWC [n,h,w,64], weights bf16 [64,3,3,64], folded BN scale / shift fp32 [64].  Bit-identical to two
+    conv2d_bn_act_nhwc_bf16 calls."""
+    x = _req(x, "x", torch.bfloat16)
+    w1_ohwi, w2_ohwi = _req(w1_ohwi, "w1_ohwi", torch.bfloat16), _req(w2_ohwi, "w2_ohwi", torch.bfloat16)
+    n, h, w, c = x.shape
+    if c != 64 or tuple(w1_ohwi.shape) != (64, 3, 3, 64) or tuple(w2_ohwi.shape) != (64, 3, 3, 64):
+        raise ValueError("basicblock64_bf16: x [n,h,w,64], weights [64,3,3,64]")
+    ps = [_req(t, nm) for t, nm in ((scale1, "scale1"), (shift1, "shift1"), (scale2, "scale2"), (shift2, "shift2"))]
+    if any(t.numel() != 64 for t in ps):
+        raise ValueError("basicblock64_bf16: scale / shift must have 64 elements")
+    y = torch.empty_like(x)
+    L.check(L.lib().rpg_basicblock64_bf16(_p(x), _p(w1_ohwi), _p(ps[0]), _p(ps[1]), _p(w2_ohwi), _p(ps[2]), _p(ps[3]), _p(y), n, h, w,
+                                          _stream()), "basicblock64_bf16")
+    return y
+
+
 def f32_to_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0) -> torch.Tensor:
     """bf16 image of the fp32 matrix x [rows][cols] (written at column col_off of `out` when given)."""
     x = _req(x, "x")
@@ -338,7 +357,7 @@ def release_scratch() -> None:
     L.check(L.lib().rpg_release_scratch(), "release_scratch")
 
 
-TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST, TUNE_FUSED_STEM, TUNE_WAVES8, TUNE_WINO_SHORT, TUNE_GNN_FUSE_AGG, TUNE_WINO_PERSIST, TUNE_BF16_TILE, TUNE_BF16_DMA, TUNE_BF16_PATCH, TUNE_BF16_WS64, TUNE_SK_MIN_ITS, TUNE_INKERNEL_FIXUP, TUNE_BF16_CHUNK, TUNE_WINO2D, TUNE_BF16_LEAN_EPI, TUNE_BF16_LINEAR_DMA, TUNE_BF16_PERSIST, TUNE_FOLD_K = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26
+TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST, TUNE_FUSED_STEM, TUNE_WAVES8, TUNE_WINO_SHORT, TUNE_GNN_FUSE_AGG, TUNE_WINO_PERSIST, TUNE_BF16_TILE, TUNE_BF16_DMA, TUNE_BF16_PATCH, TUNE_BF16_WS64, TUNE_SK_MIN_ITS, TUNE_INKERNEL_FIXUP, TUNE_BF16_CHUNK, TUNE_WINO2D, TUNE_BF16_LEAN_EPI, TUNE_BF16_LINEAR_DMA, TUNE_BF16_PERSIST, TUNE_FOLD_K, TUNE_BF16_FUSE_BLOCK = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27
 
 
 def set_tuning(key: int, value: int) -> None:

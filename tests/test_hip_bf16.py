@@ -454,3 +454,101 @@ def test_bf16_gnn_forward_vs_fp32(dev):
     m.gnn_dtype, m.encoder_dtype = "f32", "f32"
     a2, r2, _ = m(d)
     assert torch.equal(a2, a32) and torch.equal(r2, r32)
+
+
+@pytest.mark.parametrize("shape", [(3, 56, 56), (7, 14, 56), (5, 24, 40), (1, 56, 56), (40, 56, 56)])
+def test_fused_basicblock64_equals_two_convolutions(dev, shape):
+    """Round 5: conv1 + BN + ReLU + conv2 + BN + identity + ReLU of a 64-channel BasicBlock as ONE kernel
+    with the intermediate in LDS (csrc/block_bf16.inc; torchvision BasicBlock reached from modules/posenet.py:1037).  The
+    intermediate is rounded to bf16 exactly where the two-launch path stores it, so the outputs must be BIT-IDENTICAL to two
+    rpg_conv2d_bn_act_nhwc_bf16 calls: tiles straddling image boundaries (14-row images), a 40-wide map (48-slot patch rows),
+    ragged last tiles, a single image, and 40 images (245 tiles)."""
+    from relpose_gnn_amd import ops
+    n, h, w = shape
+    g = torch.Generator().manual_seed(1000 + n * h + w)
+    x = torch.randn((n, h, w, 64), generator=g).bfloat16().to(dev)
+    w1 = (torch.randn((64, 3, 3, 64), generator=g) * (2.0 / 576) ** 0.5).bfloat16().to(dev)
+    w2 = (torch.randn((64, 3, 3, 64), generator=g) * (2.0 / 576) ** 0.5).bfloat16().to(dev)
+    s1, b1 = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.2).to(dev)
+    s2, b2 = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.2).to(dev)
+    # the two-launch reference on the PATCH kernel (RPG_TUNE_BF16_PATCH = 2: wherever eligible; the dispatcher picks it by itself
+    # from 21 images of 56x56 up): the fused kernel walks K in the patch kernel's order (32-channel chunk major, tap minor);
+    # below that size the dispatcher's im2col kernel sums tap major and differs in the last bf16 bit of ~0.04 % of the outputs
+    ops.set_tuning(ops.TUNE_BF16_PATCH, 2)
+    try:
+        t = ops.conv2d_bn_act_nhwc_bf16(x, w1, s1, b1, None, stride=1, pad=1, relu=True)
+        want = ops.conv2d_bn_act_nhwc_bf16(t, w2, s2, b2, x, stride=1, pad=1, relu=True)
+    finally:
+        ops.set_tuning(ops.TUNE_BF16_PATCH, 1)
+    got = ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and bool(torch.isfinite(got.float()).all())
+    bad = (got != want).nonzero()
+    assert bad.numel() == 0, (shape, int(bad.shape[0]), bad[:5].tolist(), float((got.float() - want.float()).abs().max()))
+    # and against an fp32 reference of the block on the same bf16 operands (bf16 bar of this file's convolution tests)
+    xf = x.float().permute(0, 3, 1, 2).cpu()
+    tf = torch.relu(torch.nn.functional.conv2d(xf, w1.float().permute(0, 3, 1, 2).cpu(), padding=1) * s1.cpu().view(1, -1, 1, 1) + b1.cpu().view(1, -1, 1, 1))
+    tf = tf.bfloat16().float()                              # the intermediate is stored in bf16 by both paths
+    yf = torch.relu(torch.nn.functional.conv2d(tf, w2.float().permute(0, 3, 1, 2).cpu(), padding=1) * s2.cpu().view(1, -1, 1, 1) + b2.cpu().view(1, -1, 1, 1) + xf)
+    assert rel_err(got.float().cpu().permute(0, 3, 1, 2), yf) < 1e-2
+
+
+def test_fused_basicblock64_refuses_shapes_it_does_not_take(dev):
+    """Maps wider than 63 pixels (the 256x341 evaluation shape: 64x86 at layer 1) are outside the fused kernel's patch budget: the
+    entry point says so (RPG_ERR_BAD_ARG) and the composite forward falls back to two launches (same results either way)."""
+    from relpose_gnn_amd import _lib, ops
+    x = torch.zeros((1, 64, 86, 64), dtype=torch.bfloat16, device=dev)
+    wz = torch.zeros((64, 3, 3, 64), dtype=torch.bfloat16, device=dev)
+    v = torch.ones(64, device=dev)
+    with pytest.raises(_lib.RpgError):
+        ops.basicblock64_bf16(x, wz, v, v, wz, v, v)
+
+
+def test_bf16_encoder_with_and_without_block_fusion_is_bit_identical(dev):
+    """The bf16 model with RPG_TUNE_BF16_FUSE_BLOCK on (default) / off: 6 graphs x 8 nodes x 224x224 (layer 1: 48 images of 56x56x64
+    = 294 output tiles per fused launch); the poses are equal bit for bit."""
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd import ops
+    from relpose_gnn_amd.graph import fc_batch
+    from relpose_gnn_amd.posenet import PoseNetX_R2
+    from relpose_gnn_amd.resnet import resnet34
+    D = 2048
+    m = PoseNetX_R2(resnet34(), droprate=0.0, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D,
+                    input_img_height=224, use_gnn=True, knn=-1, use_AP=True, gnn_recursion=2)
+    m.load_state_dict(S.synth_state_dict(S.posenet_r2_param_shapes(D, D, D), seed=1))
+    m = m.to(dev).eval()
+    m.encoder_dtype = "bf16"
+    d = fc_batch(S.synth_images(48, 224, 224, seed=9), 8).to(dev)
+    outs = []
+    try:
+        for fuse in (1, 0):
+            ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, fuse)
+            a, r, _ = m(d)
+            outs.append((a.clone(), r.clone()))
+    finally:
+        ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, 1)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert bool(torch.isfinite(outs[0][0]).all()) and float(outs[0][0].abs().max()) > 0
+
+
+def test_conv_bf16_lean_epilogue_without_relu_keeps_nan(dev):
+    """the lean epilogue clamped with max(y, relu ? 0 : -inf), which turns a NaN accumulator of a NON-ReLU convolution
+    (the 1x1 downsample) into -inf where the general epilogue and the reference propagate it.  Now a select: relu = False on
+    both epilogues, one NaN pixel in the input -- the outputs agree bit for bit (NaN positions included) and the NaN is there."""
+    from relpose_gnn_amd import ops
+    x = _rand(24, 64, 28, 28, seed=71).bfloat16()
+    x[3, 5, 6, 8] = float("nan")                          # an even pixel: the stride-2 1x1 convolution samples it
+    wt = _rand(128, 64, 1, 1, seed=72, scale=(2.0 / 64) ** 0.5).bfloat16()
+    scale, shift = torch.rand(128, generator=torch.Generator().manual_seed(73)) + 0.5, _rand(128, seed=74, scale=0.1)
+    xd, wd = x.permute(0, 2, 3, 1).contiguous().to(dev), wt.permute(0, 2, 3, 1).contiguous().to(dev)
+    outs = {}
+    try:
+        for lean in (1, 0):
+            ops.set_tuning(ops.TUNE_BF16_LEAN_EPI, lean)
+            outs[lean] = ops.conv2d_bn_act_nhwc_bf16(xd, wd, scale.to(dev), shift.to(dev), None, stride=2, pad=0, relu=False)
+    finally:
+        ops.set_tuning(ops.TUNE_BF16_LEAN_EPI, 1)
+    a, b = outs[1].float().cpu(), outs[0].float().cpu()
+    assert torch.equal(torch.isnan(a), torch.isnan(b)) and int(torch.isnan(a).sum()) == 128          # output pixel (3, 4) of image 3, all channels
+    assert torch.equal(torch.nan_to_num(a, nan=0.0), torch.nan_to_num(b, nan=0.0))
+    assert float(a[~torch.isnan(a)].min()) < 0.0                                                     # really no ReLU

@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--warm", type=int, default=0, help="untimed launches before the timed ones")
     ap.add_argument("--bf16", action="store_true", help="the bf16 convolution kernels (bf16 activations / weights) instead of fp32")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="rpg_set_tuning(KEY, VALUE)")
+    ap.add_argument("--block64", action="store_true", help="bf16: the fused 64-channel BasicBlock kernel (rpg_basicblock64_bf16) against its "
+                    "two convolution launches on the same operands, interleaved (layer 1 of ResNet34: 56x56x64)")
     ap.add_argument("--dma-sweep", default="", help="bf16 only: comma-separated configuration indices of the LDS-DMA kernel; every shape "
                     "is timed with the default dispatch and with each of them (RPG_TUNE_BF16_DMA = 10 + i) interleaved in one process")
     args = ap.parse_args()
@@ -88,6 +90,26 @@ def main():
     if os.environ.get("RPG_WS64"):
         ops.set_tuning(ops.TUNE_BF16_WS64, int(os.environ["RPG_WS64"]))
     print(f"# bk={args.bk} epi={args.epi} tile={args.tile} streamk={args.sk}", flush=True)
+    if args.block64:
+        n, h, w = args.nimg, 56, 56
+        g = torch.Generator(device=dev).manual_seed(5)
+        x = torch.randn((n, h, w, 64), generator=g, device=dev).bfloat16()
+        w1 = (torch.randn((64, 3, 3, 64), generator=g, device=dev) * (2.0 / 576) ** 0.5).bfloat16()
+        w2 = (torch.randn((64, 3, 3, 64), generator=g, device=dev) * (2.0 / 576) ** 0.5).bfloat16()
+        s1, b1 = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+        s2, b2 = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+
+        def two():
+            t = ops.conv2d_bn_act_nhwc_bf16(x, w1, s1, b1, None, stride=1, pad=1, relu=True)
+            return ops.conv2d_bn_act_nhwc_bf16(t, w2, s2, b2, x, stride=1, pad=1, relu=True)
+        fl = 2 * 2.0 * n * h * w * 64 * 576
+        same = torch.equal(two(), ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2))
+        for rep in range(3):
+            m2, _ = timeit(two, args.reps)
+            m1, _ = timeit(lambda: ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2), args.reps)
+            print(f"block64 images={n}  two launches {m2*1e3:7.1f} us ({fl/m2/1e9:6.1f} TF)   fused {m1*1e3:7.1f} us ({fl/m1/1e9:6.1f} TF)   "
+                  f"ratio {m1/m2:.3f}   bit-identical {same}", flush=True)
+        return
     for name, n, h, w, cin, cout, k, s, p, res in SHAPES:
         if args.only and args.only not in name:
             continue
