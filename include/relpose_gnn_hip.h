@@ -360,6 +360,9 @@ int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
 #define RPG_TUNE_BF16_FUSE_BLOCK 27  /* bf16 encoder: 1 (default) = 64-channel identity BasicBlocks (ResNet34 layer 1) run as ONE kernel, conv1 + BN + ReLU
                                      + conv2 + BN + identity + ReLU with the intermediate activation in LDS (rpg_basicblock64_bf16; bit-identical
                                      to the two convolution launches) | 0 = two launches */
+#define RPG_TUNE_BF16_TAIL 28        /* bf16 3x3 / stride-1 convolutions on more than one round of tiles: 1 (default) = the rows beyond the last FULL round of
+                                     workgroups go to a second launch of the patch kernel with smaller tiles (160 x 256 / 256 x 128) instead of a mostly
+                                     empty round of full-size tiles (49 * 2^k pixels: 3.06 / 1.53 rounds at 512 images); same arithmetic per output | 0 = one launch */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

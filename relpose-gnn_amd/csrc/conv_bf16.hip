@@ -754,6 +754,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
 struct PatchArgs {
     const __bf16* x;
     int H, W, Cin, Nimg, M, N, tiles_n, n_tiles;
+    int m_base;                            // first output row of tile 0 (a launch may cover the rows [m_base, m_end) only: split launches)
     int P, PR, patch_bytes, n_pieces;      // slots per patch row, patch rows, bytes per patch buffer (multiple of 1 KB), 1-KB pieces
     // floor(2^32 / d) + 1 for d = H + 2, H * W, W, P / 16: the divisions of the tile set-up as one mul_hi each (exact for
     // numerator * d < 2^32; every numerator here is a piece index, a patch row or a pixel offset inside the tile: < 2^15).  Round 4: the
@@ -806,7 +807,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3, q8 = nwg >> 3, r8 = nwg & 7;
     int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-    int m0 = PS ? tile * BM : (tile / a.tiles_n) * BM;
+    int m0 = a.m_base + (PS ? tile * BM : (tile / a.tiles_n) * BM);
     const int n0 = PS ? 0 : (tile % a.tiles_n) * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1060,7 +1061,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
         RPG_PATCH_STAMP(2);                               // fragment addresses / accumulators set up: the K loop starts waiting
 
         // persistent form: the tile after this one (its geometry is computed in front of the last chunk, below)
-        const int tile_n = tile + nwg, m0_n = tile_n * BM;
+        const int tile_n = tile + nwg, m0_n = a.m_base + tile_n * BM;
         const bool has_next = PS && tile_n < a.n_tiles;
         int nf_n = 0, rf_n = 0, v0_n = 0;
         if (PS && !first_tile) {
@@ -1182,15 +1183,20 @@ int g_bf16_stages = 4;   // weight stages of the patch kernel (experiments: 3 = 
 // default two-stream schedule lives on the other stream's workgroups slipping into this launch's gaps: configs[2] 13.53-13.60 k graphs/s
 // without it, 13.26-13.39 k with it (same box, alternating runs; one-stream kernel sums equal).
 int g_bf16_persist = 0;
+int g_bf16_tail = 1;     // RPG_TUNE_BF16_TAIL: the rows beyond the last full round of tiles go to a second launch with smaller tiles
 int g_bf16_patch = 1;    // RPG_TUNE_BF16_PATCH: the patch kernel for 3x3 / stride-1 convolutions: 0 off | 1 by shape | 2 wherever eligible
 
 // The patch kernel, if the shape is eligible (3x3, stride 1, pad 1, Cin % 64 == 0, patch <= 64 pieces, 32-bit offsets, LDS fits)
+// m_begin / m_end: the launch covers the output rows [m_begin, m_end) only (m_end = 0: to M); the tiles start at m_begin
 template <int BM, int BN, int WM, int WN, int NS, bool PS = false>
-bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, const EpiB& ep, hipStream_t s) {
+bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, const EpiB& ep, hipStream_t s, int m_begin = 0, int m_end = 0) {
     if (c.KH != 3 || c.KW != 3 || c.stride != 1 || c.pad != 1 || (c.Cin & 63) || c.img_elems) return false;
     const int H = c.H, W = c.W, HW = H * W;
     PatchArgs a{};
-    a.x = c.x; a.H = H; a.W = W; a.Cin = c.Cin; a.Nimg = nimg; a.M = M; a.N = N;
+    if (m_end <= 0 || m_end > M) m_end = M;
+    if (m_begin < 0 || m_begin >= m_end) return false;
+    // a.M bounds the rows a tile may write / read as pixels: the end of this launch's range
+    a.x = c.x; a.H = H; a.W = W; a.Cin = c.Cin; a.Nimg = nimg; a.M = m_end; a.N = N; a.m_base = m_begin;
     a.tiles_n = (N + BN - 1) / BN;
     a.P = (W + 2 + 15) / 16 * 16;
     const int rows = (BM - 1) / W + 2, imgs = (BM - 1) / HW + 2;
@@ -1202,7 +1208,7 @@ bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, c
     // exactness of v_mul_hi(n, magic): n * d < 2^32 with n < patch slots (4096), patch rows + H + 2, H W + BM, H W respectively
     if ((long)(HW + BM) * HW >= (1L << 32) || (long)(a.PR + H + 2 + 2) * (H + 2) >= (1L << 32)) return false;
     constexpr int slab = 8 * 32 * ((BN / WN / 32) * 32 + 4) * 4;
-    const int tm = (M + BM - 1) / BM;
+    const int tm = (m_end - m_begin + BM - 1) / BM;
     a.n_tiles = tm * a.tiles_n;
     int lds = 2 * a.patch_bytes + NS * BN * 64 + 1024;
     int grid = a.n_tiles;
@@ -1210,7 +1216,7 @@ bool launch_patch(const ConvArgsB& c, const __bf16* w, int nimg, int M, int N, c
         // persistent form: one workgroup per CU, more than one round of tiles, one channel tile (the weight offsets carry over), the
         // epilogue slabs beside patch buffer 1 (kernel comment)
         grid = rpg::num_cus();
-        if (!ep.lean || a.tiles_n != 1 || a.n_tiles <= grid || ((long)a.n_tiles + grid) * BM >= (1L << 31)) return false;      // (the tile after the last is still an int)
+        if (!ep.lean || a.tiles_n != 1 || a.n_tiles <= grid || (long)m_begin + ((long)a.n_tiles + grid) * BM >= (1L << 31)) return false;      // (the tile after the last is still an int)
         lds = a.patch_bytes + NS * BN * 64 + 1024 + (a.patch_bytes > slab ? a.patch_bytes : slab);
     }
     if (a.n_pieces > 64 || lds > 160 * 1024 || lds < slab) return false;
@@ -1388,6 +1394,7 @@ void bf16_set_fused_stem(int on) { g_bf16_fused_stem = on; }
 void bf16_set_lean_epi(int on) { g_bf16_lean_epi = on; }
 void bf16_set_persist(int v) { g_bf16_persist = v; }
 void bf16_set_fuse_block(int v) { g_bf16_fuse_block = v; }
+void bf16_set_tail(int v) { g_bf16_tail = v; }
 void bf16_set_linear_dma(int v) { g_bf16_linear_dma = v; }
 void bf16_set_chunk(int images, int min_mb) { g_bf16_chunk = images; g_bf16_chunk_mb = min_mb; }
 #ifdef RPG_PROBE_WS64
@@ -1519,18 +1526,38 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
         // need the tall tile to put 8-16 MFMAs per wave between two barriers.  Four weight stages (next step's weight fragments
         // read before the barrier) where the LDS allows and it measured faster, else three.
         const bool big = M >= 65536 || g_bf16_patch >= 2;
+        // Tail re-tiling (round 5, RPG_TUNE_BF16_TAIL): M = 49 * 2^k pixels puts 49 * 2^j tiles on 256 CUs -- 3.06 rounds on layer 2,
+        // 1.53 on layer 3 at 512 images -- and the last, mostly empty round costs a whole tile time.  Splitting the tail tiles along
+        // K (what the fp32 Winograd kernel does) would move fp32 partial slabs of 256 KB per part through HBM: more than the round it
+        // saves.  Instead the rows beyond the last FULL round go to a second launch of the same kernel family with SMALLER tiles
+        // (160 x 256 on 8 x 1 waves / 256 x 128): one short round instead of a full one, no partial sums, same arithmetic per output.
+        const int cus = num_cus();
+        auto tail_split = [&](int bm, int bm_tail) -> int {        // rows of the main launch, or 0: do not split
+            if (!g_bf16_tail || cout > 256 || M >= (1L << 30)) return 0;
+            const long tiles = (M + bm - 1) / bm;
+            const long main_tiles = tiles / cus * cus, rem = tiles - main_tiles;
+            if (main_tiles == 0 || rem == 0) return 0;
+            const long tail_rows = M - main_tiles * bm;
+            return (tail_rows + bm_tail - 1) / bm_tail <= cus ? (int)(main_tiles * bm) : 0;
+        };
         if (g_bf16_patch == 3) {
             done = launch_patch<256, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s);
         } else if (cout > 128 && 4 * t256 >= 3L * num_cus()) {
-            done = (g_bf16_stages != 3 && launch_patch<256, 256, 2, 4, 4>(a, wp, n, (int)M, cout, ep, s)) ||
-                   launch_patch<256, 256, 2, 4, 3>(a, wp, n, (int)M, cout, ep, s);
+            const int m_main = cout <= 256 ? tail_split(256, 160) : 0;
+            done = (g_bf16_stages != 3 && launch_patch<256, 256, 2, 4, 4>(a, wp, n, (int)M, cout, ep, s, 0, m_main)) ||
+                   launch_patch<256, 256, 2, 4, 3>(a, wp, n, (int)M, cout, ep, s, 0, m_main);
+            if (done && m_main && !launch_patch<160, 256, 1, 8, 3>(a, wp, n, (int)M, cout, ep, s, m_main, 0))
+                done = launch_patch<256, 256, 2, 4, 3>(a, wp, n, (int)M, cout, ep, s, m_main, 0);
         } else if (cout > 128) {
             done = launch_patch<256, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s);
         } else if (cout > 64 && big) {
             // (the persistent form of this tile was built and measured slower -- 141 -> 179 us: at 256 VGPRs the next tile's piece
             // addresses, computed in front of the last chunk with the accumulators live, spill 65-113 registers)
-            done = (g_bf16_stages != 3 && launch_patch<512, 128, 4, 2, 4>(a, wp, n, (int)M, cout, ep, s)) ||
-                   launch_patch<512, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s);
+            const int m_main = tail_split(512, 256);
+            done = (g_bf16_stages != 3 && launch_patch<512, 128, 4, 2, 4>(a, wp, n, (int)M, cout, ep, s, 0, m_main)) ||
+                   launch_patch<512, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s, 0, m_main);
+            if (done && m_main && !launch_patch<256, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s, m_main, 0))
+                done = launch_patch<512, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s, m_main, 0);
         } else if (g_bf16_patch >= 2 || big) {
             // 64 output channels (layer 1).  Round 3 measured 232-245 us at 512 images against 205-222 us for the im2col DMA kernel
             // with two 80-KB workgroups per CU (configuration 5: they hide each other's epilogue) and kept this tile for tests only.

@@ -88,6 +88,24 @@ def gpu_local_cpus(device_index: int) -> Optional[List[int]]:
         return None
 
 
+def _core_major(cpus: Sequence[int]) -> List[int]:
+    """``cpus`` ordered core by core (a core's SMT siblings next to each other), from sysfs; plain ascending order if the
+    topology files are not there.  On the GPU hosts of this pool (2 x 64 cores, SMT on) CPU c and c + 128 are siblings: cut in
+    plain numeric order, rank 0 of a NUMA node would get cores 0-31 and rank 2 their hyper-thread twins."""
+    def key(c):
+        try:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            with open(base + "physical_package_id") as f:
+                pkg = int(f.read())
+            with open(base + "core_id") as f:
+                core = int(f.read())
+            return (pkg, core, c)
+        except Exception:
+            return (0, c, c)
+    keys = {c: key(c) for c in cpus}
+    return sorted(cpus, key=lambda c: keys[c])
+
+
 def rank_cpu_slice(local_rank: int, local_world: int, cpus: Optional[Sequence[int]] = None) -> List[int]:
     """The contiguous slice of ``cpus`` (default: this process's current affinity mask, in ascending order) that
     ``local_rank`` of ``local_world`` ranks on this host gets: equal shares, every CPU in exactly one share.  On a
@@ -98,6 +116,13 @@ def rank_cpu_slice(local_rank: int, local_world: int, cpus: Optional[Sequence[in
         return list(cpus)
     lo, hi = shard_range(len(cpus), local_rank, local_world)
     return list(cpus[lo:hi]) if hi > lo else [cpus[local_rank % len(cpus)]]
+
+
+def _slice_in_order(local_rank: int, local_world: int, ordered: Sequence[int]) -> List[int]:
+    if local_world <= 1 or not ordered:
+        return list(ordered)
+    lo, hi = shard_range(len(ordered), local_rank, local_world)
+    return list(ordered[lo:hi]) if hi > lo else [ordered[local_rank % len(ordered)]]
 
 
 def bind_rank_to_host_slice(local_rank: int, local_world: int, device_index: Optional[int] = None) -> Optional[List[int]]:
@@ -121,9 +146,9 @@ def bind_rank_to_host_slice(local_rank: int, local_world: int, device_index: Opt
             nodes = max(1, round(len(allowed) / max(1, len(near))))
             per_node = max(1, local_world // nodes)
             if near:
-                cpus = rank_cpu_slice(local_rank % per_node, per_node, near)
+                cpus = sorted(_slice_in_order(local_rank % per_node, per_node, _core_major(near)))
         if not cpus:
-            cpus = rank_cpu_slice(local_rank, local_world, allowed)
+            cpus = sorted(_slice_in_order(local_rank, local_world, _core_major(allowed)))
         os.sched_setaffinity(0, cpus)
         _BOUND = ((local_rank, local_world), cpus)
         return cpus

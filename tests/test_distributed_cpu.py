@@ -162,5 +162,5 @@ def test_rank_host_slices_partition_the_cpus():
     p.start()
     before, got, again, after = q.get(timeout=120)
     p.join(30)
-    assert got == before[len(before) // 2 + len(before) % 2:] or got == shard.rank_cpu_slice(1, 2, before)
+    assert got == sorted(shard._slice_in_order(1, 2, shard._core_major(before)))          # whole cores, SMT siblings together
     assert again == got and after == got and sorted(os.sched_getaffinity(0)) == before

@@ -500,7 +500,7 @@ def test_fused_basicblock64_refuses_shapes_it_does_not_take(dev):
     x = torch.zeros((1, 64, 86, 64), dtype=torch.bfloat16, device=dev)
     wz = torch.zeros((64, 3, 3, 64), dtype=torch.bfloat16, device=dev)
     v = torch.ones(64, device=dev)
-    with pytest.raises(_lib.RpgError):
+    with pytest.raises((ValueError, _lib.RpgError)):
         ops.basicblock64_bf16(x, wz, v, v, wz, v, v)
 
 
@@ -552,3 +552,31 @@ def test_conv_bf16_lean_epilogue_without_relu_keeps_nan(dev):
     assert torch.equal(torch.isnan(a), torch.isnan(b)) and int(torch.isnan(a).sum()) == 128          # output pixel (3, 4) of image 3, all channels
     assert torch.equal(torch.nan_to_num(a, nan=0.0), torch.nan_to_num(b, nan=0.0))
     assert float(a[~torch.isnan(a)].min()) < 0.0                                                     # really no ReLU
+
+
+@pytest.mark.parametrize("n,h,w,c,res", [(400, 14, 14, 256, True), (400, 28, 28, 128, False), (340, 14, 14, 256, False)])
+def test_patch_kernel_tail_retiling_is_bit_identical(dev, n, h, w, c, res):
+    """Round 5: on more than one round of tiles the rows beyond the last FULL round go to a second launch
+    of the patch kernel with smaller tiles (RPG_TUNE_BF16_TAIL = 1: 160 x 256 on 8 x 1 waves for layer 3, 256 x 128 for layer 2)
+    instead of a mostly empty round of full-size tiles.  Same K order, same MFMA, same epilogue: bit-identical to the single
+    launch (= 0), with and without a residual; and within the bf16 bar of F.conv2d on a sample of images from both parts."""
+    from relpose_gnn_amd import ops
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn((n, h, w, c), generator=g).bfloat16().to(dev)
+    wt = (torch.randn((c, 3, 3, c), generator=g) * (2.0 / (9 * c)) ** 0.5).bfloat16().to(dev)
+    sc, sh = (torch.rand(c, generator=g) + 0.5).to(dev), (torch.randn(c, generator=g) * 0.1).to(dev)
+    r = torch.randn((n, h, w, c), generator=g).bfloat16().to(dev) if res else None
+    outs = {}
+    try:
+        for tail in (1, 0):
+            ops.set_tuning(ops.TUNE_BF16_TAIL, tail)
+            outs[tail] = ops.conv2d_bn_act_nhwc_bf16(x, wt, sc, sh, r, stride=1, pad=1, relu=True)
+    finally:
+        ops.set_tuning(ops.TUNE_BF16_TAIL, 1)
+    assert torch.equal(outs[1], outs[0])
+    for i in (0, n // 2, n - 1):                               # first image, one in the middle, the last (tail launch)
+        ref = F.conv2d(x[i:i + 1].float().permute(0, 3, 1, 2).cpu(), wt.float().permute(0, 3, 1, 2).cpu(), padding=1)
+        ref = ref * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1)
+        if res:
+            ref = ref + r[i:i + 1].float().permute(0, 3, 1, 2).cpu()
+        assert rel_err(outs[1][i:i + 1].float().cpu().permute(0, 3, 1, 2), F.relu(ref)) < 1e-2

@@ -68,6 +68,35 @@ def child(args):
                       "workers": pipe.workers, "cpus": len(cpus) if cpus else len(os.sched_getaffinity(0))}), flush=True)
 
 
+def memcpy_probe(seconds: float):
+    """Host characterisation: aggregate pageable -> pageable copy rate of T numpy threads (64-MB buffers, each thread its own pair;
+    the GIL is released inside np.copyto), T = 1 .. 128: what the staging threads of ALL ranks can share on this host."""
+    import threading
+    import numpy as np
+    out = []
+    for threads in (1, 4, 16, 32, 64, 128):
+        src = [np.ones(16 << 20, dtype=np.float32) for _ in range(threads)]
+        dst = [np.empty_like(a) for a in src]
+        counts = [0] * threads
+        stop = time.perf_counter() + seconds
+
+        def work(i):
+            while time.perf_counter() < stop:
+                np.copyto(dst[i], src[i])
+                counts[i] += 1
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        dt = time.perf_counter() - t0
+        rec = {"memcpy_threads": threads, "read_gb_per_s": round(sum(counts) * (64 << 20) / dt / 1e9, 1), "buffers_mb": 64}
+        print(json.dumps(rec), flush=True)
+        out.append(rec)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ranks", type=int, default=8)
@@ -80,7 +109,10 @@ def main():
     ap.add_argument("--bind", type=int, default=1)
     ap.add_argument("--no-h2d", action="store_true")
     ap.add_argument("--start-at", type=float, default=0.0)
+    ap.add_argument("--memcpy-probe", action="store_true", help="only the host copy-rate characterisation (no GPU, no ranks)")
     args = ap.parse_args()
+    if args.memcpy_probe:
+        return memcpy_probe(min(args.seconds, 3.0))
     if args.rank >= 0:
         return child(args)
     out = []
