@@ -360,9 +360,11 @@ int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
 #define RPG_TUNE_BF16_FUSE_BLOCK 27  /* bf16 encoder: 1 (default) = 64-channel identity BasicBlocks (ResNet34 layer 1) run as ONE kernel, conv1 + BN + ReLU
                                      + conv2 + BN + identity + ReLU with the intermediate activation in LDS (rpg_basicblock64_bf16; bit-identical
                                      to the two convolution launches) | 0 = two launches */
-#define RPG_TUNE_BF16_TAIL 28        /* bf16 3x3 / stride-1 convolutions on more than one round of tiles: 1 (default) = the rows beyond the last FULL round of
-                                     workgroups go to a second launch of the patch kernel with smaller tiles (160 x 256 / 256 x 128) instead of a mostly
-                                     empty round of full-size tiles (49 * 2^k pixels: 3.06 / 1.53 rounds at 512 images); same arithmetic per output | 0 = one launch */
+#define RPG_TUNE_BF16_TAIL 28        /* bf16 3x3 / stride-1 convolutions on more than one round of tiles: the rows beyond the last FULL round of workgroups
+                                     go to a second launch of the patch kernel with smaller tiles instead of a mostly empty round of full-size ones
+                                     (49 * 2^k pixels: 3.06 / 1.53 rounds at 512 images); same arithmetic per output, bit-identical.  Bit 0 (default
+                                     on): 512 x 128 -> 256 x 128 tiles (layer 2: -4..5 %); bit 1 (off): 256 x 256 -> 160 x 256 (layer 3: measured
+                                     no gain); 0 = always one launch */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -838,7 +838,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
         rf = m0_ - nf * HW;                                          // pixel of m0 inside its image
         v0_ = nf * HV + div_magic(rf, a.mg_w);                       // = v(m0) - 1: the row above the tile's first pixel
         const int s_l = lane >> 2;                                   // the lane's slot inside its piece
-        const int lc8 = 8 * ((lane & 3) ^ ((s_l >> 2) & 3));         // (slot >> 2) & 3 == (s_l >> 2) & 3: pieces start on multiples of 16 slots
+        const int lc0 = (lane & 3) ^ ((s_l >> 2) & 3);               // (slot >> 2) & 3 == (s_l >> 2) & 3: pieces start on multiples of 16 slots
         const int p16 = P >> 4;                                      // pieces per patch row
         const int vbase = v0_ - nf * HV;                             // patch row 0 relative to the first image's virtual rows
 #pragma unroll
@@ -846,6 +846,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
             const int q = wave + NW * t;                             // uniform
             const int prow = div_magic(q, a.mg_p16);
             const int col0 = (q - prow * p16) * 16;
+            // Row-parity term of the swizzle (round 5): physical chunk = logical ^ ((slot >> 2) & 3) ^ 2 (patch row & 1).  With P a
+            // multiple of 16 the same column of two ADJACENT patch rows lies a multiple of 16 slots apart -- the same banks under the
+            // slot term alone -- and on 14-wide maps (P = 16) a fragment's 32 consecutive pixels cover 2.3 rows: lanes l and l + 14
+            // of one ds_read_b128 lane group hit the same 16 bytes' banks (r4 PMC: SQ_LDS_BANK_CONFLICT = 45 % of the LDS cycles of the
+            // 256 x 256 kernel).  Parity is XOR-decomposable over the kernel row: tap kh of a pixel reads row + kh, i.e. the table
+            // entry of the OTHER k group when kh is odd (read_a) -- no extra registers, no extra instructions.
+            const int lc8 = 8 * (lc0 ^ (2 * (prow & 1)));
             const int vrel = vbase + prow;                           // < PR + HV
             const int nrel = div_magic(vrel, a.mg_hv);
             const int rr = vrel - nrel * HV - 1;
@@ -909,7 +916,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
     // loop and spilled them (100 VGPRs in the four-stage form)
     auto read_a = [&](int set, int g, int i, int tap) {
         const unsigned aoff = (unsigned)((tap / 3) * P * 64);                             // wave-uniform
-        fr[set][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds_raw + (a3[i][tap % 3][g] + aoff)));
+        fr[set][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds_raw + (a3[i][tap % 3][g ^ ((tap / 3) & 1)] + aoff)));
     };
     auto flip_patch = [&](int buf) {                           // after a chunk on buffer `buf`: the next chunk reads the other one
         const unsigned d = buf == 0 ? off_b1 : 0u - off_b1;
@@ -1043,11 +1050,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_bf16_patch_kernel(PatchA
             m = m < a.M ? m : a.M - 1;
             const int rel = rem_first + (m - m0);                    // pixel offset from the first image's origin: < HW + BM
             const int nr = div_magic(rel, a.mg_hw), rem = rel - nr * HW, r = div_magic(rem, a.mg_w), c = rem - r * W;
-            const int s0 = ((n_first + nr) * HV + r - v0) * P + c;
+            const int prow0 = (n_first + nr) * HV + r - v0;          // patch row of the pixel's kh = 0 taps
+            const int s0 = prow0 * P + c;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int t = s0 + kw;
-                const int e = half ^ ((t >> 2) & 3);
+                const int e = half ^ ((t >> 2) & 3) ^ (2 * (prow0 & 1));
                 a3[i][kw][0] = (unsigned)(t * 64 + 16 * e);
                 a3[i][kw][1] = (unsigned)(t * 64 + 16 * (e ^ 2));
             }
@@ -1183,7 +1191,9 @@ int g_bf16_stages = 4;   // weight stages of the patch kernel (experiments: 3 = 
 // default two-stream schedule lives on the other stream's workgroups slipping into this launch's gaps: configs[2] 13.53-13.60 k graphs/s
 // without it, 13.26-13.39 k with it (same box, alternating runs; one-stream kernel sums equal).
 int g_bf16_persist = 0;
-int g_bf16_tail = 1;     // RPG_TUNE_BF16_TAIL: the rows beyond the last full round of tiles go to a second launch with smaller tiles
+int g_bf16_tail = 1;     // RPG_TUNE_BF16_TAIL: bit 0 (default): 512 x 128 launches hand the rows beyond the last full round to 256 x 128 tiles (layer 2 at 512
+                         // images: -4..5 %); bit 1: 256 x 256 launches likewise to 160 x 256 tiles (layer 3: measured no gain -- the partly empty
+                         // second round of the single launch already runs 1.46x faster per tile: the kernels are bound chip-wide, not per CU)
 int g_bf16_patch = 1;    // RPG_TUNE_BF16_PATCH: the patch kernel for 3x3 / stride-1 convolutions: 0 off | 1 by shape | 2 wherever eligible
 
 // The patch kernel, if the shape is eligible (3x3, stride 1, pad 1, Cin % 64 == 0, patch <= 64 pieces, 32-bit offsets, LDS fits)
@@ -1394,7 +1404,7 @@ void bf16_set_fused_stem(int on) { g_bf16_fused_stem = on; }
 void bf16_set_lean_epi(int on) { g_bf16_lean_epi = on; }
 void bf16_set_persist(int v) { g_bf16_persist = v; }
 void bf16_set_fuse_block(int v) { g_bf16_fuse_block = v; }
-void bf16_set_tail(int v) { g_bf16_tail = v; }
+void bf16_set_tail(int v) { g_bf16_tail = v & 3; }
 void bf16_set_linear_dma(int v) { g_bf16_linear_dma = v; }
 void bf16_set_chunk(int images, int min_mb) { g_bf16_chunk = images; g_bf16_chunk_mb = min_mb; }
 #ifdef RPG_PROBE_WS64
@@ -1543,7 +1553,7 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
         if (g_bf16_patch == 3) {
             done = launch_patch<256, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s);
         } else if (cout > 128 && 4 * t256 >= 3L * num_cus()) {
-            const int m_main = cout <= 256 ? tail_split(256, 160) : 0;
+            const int m_main = (g_bf16_tail & 2) && cout <= 256 ? tail_split(256, 160) : 0;
             done = (g_bf16_stages != 3 && launch_patch<256, 256, 2, 4, 4>(a, wp, n, (int)M, cout, ep, s, 0, m_main)) ||
                    launch_patch<256, 256, 2, 4, 3>(a, wp, n, (int)M, cout, ep, s, 0, m_main);
             if (done && m_main && !launch_patch<160, 256, 1, 8, 3>(a, wp, n, (int)M, cout, ep, s, m_main, 0))
@@ -1553,7 +1563,7 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
         } else if (cout > 64 && big) {
             // (the persistent form of this tile was built and measured slower -- 141 -> 179 us: at 256 VGPRs the next tile's piece
             // addresses, computed in front of the last chunk with the accumulators live, spill 65-113 registers)
-            const int m_main = tail_split(512, 256);
+            const int m_main = (g_bf16_tail & 1) ? tail_split(512, 256) : 0;
             done = (g_bf16_stages != 3 && launch_patch<512, 128, 4, 2, 4>(a, wp, n, (int)M, cout, ep, s, 0, m_main)) ||
                    launch_patch<512, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s, 0, m_main);
             if (done && m_main && !launch_patch<256, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s, m_main, 0))
@@ -1666,7 +1676,7 @@ static int resnet_forward_bf16_impl(const void* const* tensors, int n_tensors, c
     void* pool = take((size_t)n * planes[3] * 2);
 
     int rc, ti = 0;
-    if (stem_pack && g_bf16_fused_stem && rpg::stem_pool_bf16_supported(h, w, planes[0])) {
+    if (stem_pack && g_bf16_fused_stem && rpg::stem_pool_bf16_supported(n, h, w, planes[0])) {
         // fp32 NCHW -> conv7x7/2 + BN + ReLU + maxpool3x3/2 -> pooled bf16 NHWC, one kernel
         if ((rc = rpg::launch_stem_pool_bf16(x_nchw_any, x_is_bf16, stem_pack, (const float*)tensors[1], (const float*)tensors[2], buf[0],
                                              n, h, w, s)) != RPG_OK)
@@ -1786,7 +1796,7 @@ extern "C" int rpg_resnet_forward_bf16(const void* const* tensors, int n_tensors
 }
 
 // the same forward on node images that are already bf16 (rounded from fp32 on the host, so that the H2D copy is half the size);
-// needs the fused stem's operands as the optional last tensor, RPG_ERR_BAD_ARG otherwise
+// with or without the fused stem's operands (the three-kernel stem's re-layout pass takes bf16 pixels too, round 4)
 extern "C" int rpg_resnet_forward_bf16_xbf16(const void* const* tensors, int n_tensors, const int* blocks, const int* planes,
                                              int feat_dim, const void* x_nchw_bf16, int n, int h, int w, float* feat, void* workspace,
                                              size_t workspace_bytes, void* stream) {

@@ -6,6 +6,8 @@
 
 #include "../../include/relpose_gnn_hip.h"
 
+#include "rpg_coherent.h"      // agent-scope partial-slab accesses + arrival ticket (device code of winograd.hip / gemm_engine.inc)
+
 namespace rpg {
 
 // Last launch error text (thread local), exposed through rpg_last_error().
@@ -30,39 +32,6 @@ void timing_end(int slot, double work, hipStream_t s, double executed = 0.0);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// Agent-scope ("sc1") 16-byte accesses for data that one workgroup writes and ANOTHER workgroup of the SAME launch reads
-// (the partial tiles of the split-K / stream-K launches, combined by the last-arriving workgroup).  The L2 caches of the 8
-// XCDs are not coherent with each other for ordinary accesses; the portable way -- __threadfence() = buffer_wbl2 + buffer_inv
-// of the whole L2 -- was measured at 2.2x the step time (round 4: 23.0 vs 10.7 ms at configs[1]).  An sc1 store is written
-// through to memory and an sc1 load does not hit a stale line, which is how agent-scope atomics are coherent on gfx942 /
-// gfx950; with ONLY such accesses to the slabs, ordering needs no cache maintenance: the writers wait for their stores
-// (s_waitcnt vmcnt(0)) before the ticket atomic, the reader loads after its own ticket atomic has returned.
-// cache-policy immediate of the raw buffer intrinsics on gfx940+: bit 0 = sc0, bit 1 = nt, bit 4 = sc1.
-typedef unsigned int rpg_u32x4 __attribute__((ext_vector_type(4)));
-constexpr int kAuxAgentScope = 16;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t agent_rsrc(const float* base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ void agent_store_f4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned s_off, const float4& v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rpg_u32x4, v), r, byte_off, s_off, kAuxAgentScope);
-}
-__device__ __forceinline__ float4 agent_load_f4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned s_off) {
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, s_off, kAuxAgentScope));
-}
-// Ticket of the arrival counter: true for the workgroup that completes the count.  Every thread of the workgroup calls it
-// after its slab stores; `flag` = an int of LDS nobody is using.  The counter goes back to zero for the next launch.
-__device__ __forceinline__ bool last_arriver(unsigned* counter, unsigned contributors, int* flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's sc1 slab stores have been written through
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = old + 1u == contributors;
-        if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = last;
-    }
-    __syncthreads();
-    return *flag != 0;
-}
 
 // ---- internal launchers shared between the fine-grained C ABI and the composite forwards ----
 struct GatherSrc {
@@ -93,7 +62,7 @@ constexpr size_t kWorkspaceSkew = 260 * 1024 + 4096;
 // counters (optional out): the block's arrival counters -- 4096 unsigned, zero between launches (see gemm_f32.hip) -- for the
 // in-kernel combine of split tiles by the last-arriving workgroup
 float* stream_scratch(hipStream_t s, size_t bytes, unsigned** counters = nullptr);
-bool inkernel_fixup_enabled();            // RPG_TUNE_INKERNEL_FIXUP (default on)
+bool inkernel_fixup_enabled();            // RPG_TUNE_INKERNEL_FIXUP bit 1 (Winograd tail tiles); OFF by default (measured slower)
 struct ScratchScope {
     ScratchScope(void* p, size_t bytes, hipStream_t s);       // zeroes the slice's counter header on s (one memset node per call)
     ~ScratchScope();
@@ -133,7 +102,7 @@ void bf16_set_fuse_block(int v);
 void bf16_set_tail(int v);
 void bf16_set_linear_dma(int v);
 int bf16_set_ws64(int v);      // RPG_OK, or RPG_ERR_BAD_ARG for v != 0 in a build without the probe kernel (tools/probes/conv3x3_bf16_ws64.inc)
-bool stem_pool_bf16_supported(int h, int w, int cout);
+bool stem_pool_bf16_supported(int n, int h, int w, int cout);      // incl. the ranges the kernel's magic divisions are exact for
 int launch_stem_pool_bf16(const void* x_nchw, int x_is_bf16, const void* wpack, const float* scale, const float* shift, void* out, int n, int h,
                           int w, hipStream_t s);
 int launch_f32_to_bf16(const float* src, int ld_src, void* dst, int ld_dst, int col_off, long rows, int cols, hipStream_t s);

@@ -236,16 +236,10 @@ __global__ __launch_bounds__(SB_NT) __attribute__((amdgpu_waves_per_eu(3, 3))) v
 
 namespace rpg {
 
-bool stem_pool_bf16_supported(int h, int w, int cout) { return cout == 64 && h >= 1 && w >= 1; }
-
-// wpack: [11][2][64] x 8 bf16 (params.pack_stem_bf16); scale / shift: the folded BatchNorm affine (fp32)
-int launch_stem_pool_bf16(const void* x_nchw, int x_is_bf16, const void* wpack, const float* scale, const float* shift, void* out,
-                          int n, int h, int w, hipStream_t s) {
-    if (!x_nchw || !wpack || !scale || !shift || !out || n <= 0 || h <= 0 || w <= 0 || !aligned16(out) || !aligned16(wpack))
-        return RPG_ERR_BAD_ARG;
-    StemBArgs a{};
-    a.x = x_nchw; a.wpack = reinterpret_cast<const uint4*>(wpack); a.scale = scale; a.shift = shift;
-    a.out = reinterpret_cast<__bf16*>(out);
+// tile geometry + the ranges the kernel's magic divisions are exact for; false = this (n, h, w) is not for the fused kernel
+// (the composite forward then takes the three-kernel stem: ADVICE r4 -- the launcher used to fail with RPG_ERR_BAD_ARG instead)
+static bool stem_pool_bf16_geometry(int n, int h, int w, StemBArgs& a, int& grid) {
+    if (n <= 0 || h <= 0 || w <= 0) return false;
     a.N = n; a.H = h; a.W = w;
     a.Hc = (h + 6 - 7) / 2 + 1; a.Wc = (w + 6 - 7) / 2 + 1;
     a.Hp = (a.Hc + 2 - 3) / 2 + 1; a.Wp = (a.Wc + 2 - 3) / 2 + 1;
@@ -255,7 +249,32 @@ int launch_stem_pool_bf16(const void* x_nchw, int x_is_bf16, const void* wpack, 
     a.RW = 2 * a.TWp + 1;
     a.nfrag = (CR * a.RW + 31) / 32;
     const long total = (long)n * a.tiles_y * a.tiles_x;
-    if (total >= (1L << 31) || (long)n * 3 * h * w >= (1L << 40)) return RPG_ERR_BAD_ARG;
+    if (total >= (1L << 31) || (long)n * 3 * h * w >= (1L << 40)) return false;
+    grid = (int)(total < (long)SB_WGS_PER_CU * num_cus() ? total : (long)SB_WGS_PER_CU * num_cus());
+    a.nxcd = (grid % 8 == 0 && n >= 64) ? 8 : 1;
+    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((1ULL << 32) / (unsigned)d) + 1u; };      // 0: divisor 1 (2^32 + 1 does not fit)
+    a.mg_rw = magic(a.RW); a.mg_tpi = magic(a.tiles_y * a.tiles_x); a.mg_tx = magic(a.tiles_x);
+    // v_mul_hi exactness needs numerator * divisor < 2^32: the tile index lt < (images + grid) * tiles per image
+    return (long)((long)n / a.nxcd + 1 + grid) * a.tiles_y * a.tiles_x * a.tiles_y * a.tiles_x < (1L << 32);
+}
+
+bool stem_pool_bf16_supported(int n, int h, int w, int cout) {
+    StemBArgs a{};
+    int grid = 0;
+    return cout == 64 && stem_pool_bf16_geometry(n, h, w, a, grid);
+}
+
+// wpack: [11][2][64] x 8 bf16 (params.pack_stem_bf16); scale / shift: the folded BatchNorm affine (fp32)
+int launch_stem_pool_bf16(const void* x_nchw, int x_is_bf16, const void* wpack, const float* scale, const float* shift, void* out,
+                          int n, int h, int w, hipStream_t s) {
+    if (!x_nchw || !wpack || !scale || !shift || !out || n <= 0 || h <= 0 || w <= 0 || !aligned16(out) || !aligned16(wpack))
+        return RPG_ERR_BAD_ARG;
+    StemBArgs a{};
+    int grid = 0;
+    if (!stem_pool_bf16_geometry(n, h, w, a, grid)) return RPG_ERR_BAD_ARG;
+    const long total = (long)n * a.tiles_y * a.tiles_x;
+    a.x = x_nchw; a.wpack = reinterpret_cast<const uint4*>(wpack); a.scale = scale; a.shift = shift;
+    a.out = reinterpret_cast<__bf16*>(out);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     static bool attr[64] = {};
@@ -266,12 +285,6 @@ int launch_stem_pool_bf16(const void* x_nchw, int x_is_bf16, const void* wpack, 
                                   SB_LDS_BYTES);
         attr[dev] = true;
     }
-    const int grid = (int)(total < (long)SB_WGS_PER_CU * num_cus() ? total : (long)SB_WGS_PER_CU * num_cus());
-    a.nxcd = (grid % 8 == 0 && n >= 64) ? 8 : 1;
-    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((1ULL << 32) / (unsigned)d) + 1u; };      // 0: divisor 1 (2^32 + 1 does not fit)
-    a.mg_rw = magic(a.RW); a.mg_tpi = magic(a.tiles_y * a.tiles_x); a.mg_tx = magic(a.tiles_x);
-    // v_mul_hi exactness needs numerator * divisor < 2^32: the tile index lt < (images + grid) * tiles per image
-    if ((long)((long)n / a.nxcd + 1 + grid) * a.tiles_y * a.tiles_x * a.tiles_y * a.tiles_x >= (1L << 32)) return RPG_ERR_BAD_ARG;
     const int slot = timing_begin(RPG_TIMER_CONV, s);
     if (x_is_bf16) hipLaunchKernelGGL(stem_pool_bf16_kernel<__bf16>, dim3(grid), dim3(SB_NT), SB_LDS_BYTES, s, a);
     else hipLaunchKernelGGL(stem_pool_bf16_kernel<float>, dim3(grid), dim3(SB_NT), SB_LDS_BYTES, s, a);

@@ -92,7 +92,7 @@ class _InputPipeline:
     read device buffer k is done; the copy stream may overwrite it).  Graphs whose ``x`` is already pinned skip the staging
     copy; graphs already on the device skip the pipeline altogether (``evaluate_stream`` collates them on the device)."""
 
-    def __init__(self, device, rows: int, row_floats: int, dtype=torch.float32):
+    def __init__(self, device, rows: int, row_floats: int, dtype=torch.float32, local_world: int = 1):
         # dtype = torch.bfloat16: the images are ROUNDED TO bf16 WHILE THEY ARE STAGED (the bf16 encoder rounds its fp32 input
         # first thing, so the forward is bit-identical) and the H2D copy is half the size -- at 256x341 the fp32 copy of a
         # 64-graph micro-batch (537 MB, ~13.7 ms at the 39 GB/s this host reaches) outlasts the bf16 forward (9 ms)
@@ -103,8 +103,15 @@ class _InputPipeline:
         self.host_np = [t.numpy() for t in self.host] if dtype == torch.float32 else None
         import os
         from concurrent.futures import ThreadPoolExecutor
-        # 8 threads reach the ~40 GB/s the host moves (memcpy for fp32 staging, rpg_host_f32_to_bf16 for bf16 staging)
-        self.workers = max(1, min(int(os.environ.get("RPG_STAGE_WORKERS", "0")) or (8 if dtype == torch.float32 else 16), max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2) // 2)))
+        # Staging threads.  One rank alone: 8 threads reach the ~40 GB/s a single fp32 stream needs, 16 the bf16 stream's ~55 GB/s
+        # (memcpy for fp32 staging, rpg_host_f32_to_bf16 for bf16 staging).  But the host's copy rate PEAKS at ~16 threads IN ALL
+        # and collapses beyond (2 x EPYC 9575F, profiles/r5_stage_scale_*.jsonl: numpy copies 273 GB/s with 16 threads, 81 with 64,
+        # 49 with 128; eight ranks' pipelines together stage 55 GB/s with 16 threads each, 73 with 8, 136 with 4, 200 with TWO),
+        # so the ranks of one host share that budget: 16 // local_world threads per rank, at least 2.
+        own = 8 if dtype == torch.float32 else 16
+        share = max(2, 16 // max(1, int(local_world)))
+        avail = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2) // 2)
+        self.workers = max(1, min(int(os.environ.get("RPG_STAGE_WORKERS", "0")) or min(own, share), avail))
         self.pool = ThreadPoolExecutor(max_workers=self.workers) if self.workers > 1 else None
         self.dev = [torch.empty((rows, row_floats), dtype=dtype, device=device) for _ in range(2)]
         self.sent = [torch.cuda.Event() for _ in range(2)]
@@ -208,7 +215,10 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
     accepts, i.e. True for the bf16 encoder with its fused stem): host-resident images are rounded to bf16 while they are staged."""
     from .shard import bind_rank_to_host_slice, gather_rows, shard_counts, shard_range
     pose_m, pose_s = np.asarray(pose_m, dtype=np.float64), np.asarray(pose_s, dtype=np.float64)
+    local_world = 1
     if world > 1 and torch.device(device).type == "cuda":
+        import os as _os
+        local_world = int(_os.environ.get("LOCAL_WORLD_SIZE", world))
         # one process per GPU on a shared host: this rank's staging threads and pinned buffers stay on its share of the
         # cores / its GPU's NUMA node (shard.bind_rank_to_host_slice; RPG_BIND_RANKS=0 switches it off).  LOCAL_* from the
         # launcher when it set them (ranks of other nodes do not share this host)
@@ -237,7 +247,7 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
                 if pipe is not None:
                     torch.cuda.synchronize(device)                  # a larger buffer pair replaces one that is in flight
                 cap = max(rows, max(g.x.shape[0] for g in chunk) * micro_batch)
-                pipe = _InputPipeline(torch.device(device), cap, width, h2d_dtype)
+                pipe = _InputPipeline(torch.device(device), cap, width, h2d_dtype, local_world)
             x_dev = pipe.stage(k, chunk)
             h2d_bytes += x_dev.numel() * x_dev.element_size()
             batch = _collate_on_device(chunk, x_dev, device)

@@ -39,7 +39,7 @@ def child(args):
     gen = torch.Generator().manual_seed(rank)
     ei = fc_edge_index(nodes)
     pool = [Data(x=torch.randn((nodes, 3 * h * w), generator=gen), edge_index=ei, y=None) for _ in range(args.pool)]   # pageable, first touched HERE (after binding)
-    pipe = _InputPipeline(dev, mb * nodes, 3 * h * w, dtype)
+    pipe = _InputPipeline(dev, mb * nodes, 3 * h * w, dtype, world)              # the product default: 16 // ranks staging threads (RPG_STAGE_WORKERS overrides)
     if args.no_h2d:
         class _NoCopy:                                   # staging only: the pinned buffer is filled, nothing is sent
             def copy_(self, *a, **k):
@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--bind", type=int, default=1)
     ap.add_argument("--no-h2d", action="store_true")
     ap.add_argument("--start-at", type=float, default=0.0)
+    ap.add_argument("--workers", default="", help="comma-separated staging-thread counts per rank to sweep (RPG_STAGE_WORKERS); default: the pipeline's own")
+    ap.add_argument("--only-ranks", action="store_true", help="skip the single-rank rows")
     ap.add_argument("--memcpy-probe", action="store_true", help="only the host copy-rate characterisation (no GPU, no ranks)")
     args = ap.parse_args()
     if args.memcpy_probe:
@@ -116,16 +118,19 @@ def main():
     if args.rank >= 0:
         return child(args)
     out = []
-    for ranks in sorted({1, args.ranks}):
-        for no_h2d in (True, False):
-            for bind in (1, 0):
+    sweep = [int(v) for v in args.workers.split(",") if v.strip()] or [0]
+    for ranks in ([args.ranks] if args.only_ranks else sorted({1, args.ranks})):
+      for workers in sweep:
+        for no_h2d in ((True,) if args.workers else (True, False)):
+            for bind in ((1,) if args.workers else (1, 0)):
                 if ranks == 1 and bind == 0:
                     continue
                 start = time.time() + 60.0 + 2.0 * ranks                   # children import torch (~seconds each) before the deadline
                 procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rank", str(r), "--ranks", str(ranks), "--dtype", args.dtype,
                                            "--shape", args.shape, "--micro-batch", str(args.micro_batch), "--pool", str(args.pool),
                                            "--seconds", str(args.seconds), "--bind", str(bind), "--start-at", str(start)] + (["--no-h2d"] if no_h2d else []),
-                                          stdout=subprocess.PIPE, text=True, env=dict(os.environ, RPG_BIND_RANKS=str(bind))) for r in range(ranks)]
+                                          stdout=subprocess.PIPE, text=True,
+                                          env=dict(os.environ, RPG_BIND_RANKS=str(bind), **({"RPG_STAGE_WORKERS": str(workers)} if workers else {}))) for r in range(ranks)]
                 recs = []
                 for p in procs:
                     o, _ = p.communicate(timeout=600)
