@@ -80,6 +80,22 @@ def errors(pred_poses: np.ndarray, targ_poses: np.ndarray) -> EvalResult:
     return EvalResult(pred_poses, targ_poses, t_loss, q_loss)
 
 
+def staging_workers(fp32_staging: bool, local_world: int = 1, available: Optional[int] = None, override: Optional[str] = None) -> int:
+    """Staging threads of one rank's input pipeline.  One rank alone: 8 threads reach the ~40 GB/s a single fp32 stream needs, 16
+    the bf16 stream's ~55 GB/s (memcpy for fp32 staging, rpg_host_f32_to_bf16 for bf16 staging).  But the host's copy rate PEAKS
+    at ~16 threads IN ALL and collapses beyond (2 x EPYC 9575F, profiles/r5_stage_scale_*.jsonl: numpy copies 273 GB/s with 16
+    threads, 81 with 64, 49 with 128; eight ranks' pipelines together stage 55 GB/s with 16 threads each, 73 with 8, 136 with 4,
+    200 with TWO), so the ranks of one host share that budget: 16 // local_world threads per rank, at least 2 -- never more than
+    the CPUs the process may run on.  RPG_STAGE_WORKERS (``override``) fixes the count."""
+    import os
+    own = 8 if fp32_staging else 16
+    share = max(2, 16 // max(1, int(local_world)))
+    if available is None:
+        available = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2) // 2
+    forced = int((os.environ.get("RPG_STAGE_WORKERS", "0") if override is None else override) or 0)
+    return max(1, min(forced or min(own, share), max(1, int(available))))
+
+
 class _InputPipeline:
     """Host -> device staging of the node images of an evaluation stream, double buffered.
 
@@ -103,15 +119,7 @@ class _InputPipeline:
         self.host_np = [t.numpy() for t in self.host] if dtype == torch.float32 else None
         import os
         from concurrent.futures import ThreadPoolExecutor
-        # Staging threads.  One rank alone: 8 threads reach the ~40 GB/s a single fp32 stream needs, 16 the bf16 stream's ~55 GB/s
-        # (memcpy for fp32 staging, rpg_host_f32_to_bf16 for bf16 staging).  But the host's copy rate PEAKS at ~16 threads IN ALL
-        # and collapses beyond (2 x EPYC 9575F, profiles/r5_stage_scale_*.jsonl: numpy copies 273 GB/s with 16 threads, 81 with 64,
-        # 49 with 128; eight ranks' pipelines together stage 55 GB/s with 16 threads each, 73 with 8, 136 with 4, 200 with TWO),
-        # so the ranks of one host share that budget: 16 // local_world threads per rank, at least 2.
-        own = 8 if dtype == torch.float32 else 16
-        share = max(2, 16 // max(1, int(local_world)))
-        avail = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2) // 2)
-        self.workers = max(1, min(int(os.environ.get("RPG_STAGE_WORKERS", "0")) or min(own, share), avail))
+        self.workers = staging_workers(dtype == torch.float32, local_world)
         self.pool = ThreadPoolExecutor(max_workers=self.workers) if self.workers > 1 else None
         self.dev = [torch.empty((rows, row_floats), dtype=dtype, device=device) for _ in range(2)]
         self.sent = [torch.cuda.Event() for _ in range(2)]

@@ -216,3 +216,36 @@ def test_reference_written_checkpoint_and_sample(golden_dir):
     a, r, _ = O.posenet_forward(sd, d.x, d.edge_index, 32, 2)
     assert float((a - torch.from_numpy(g["abs"][:8])).abs().max()) < 1e-5 * float(np.abs(g["abs"]).max())
     assert float((r - torch.from_numpy(g["rel"][:56])).abs().max()) < 1e-5 * float(np.abs(g["rel"]).max())
+
+
+def test_staging_thread_budget_is_shared_by_the_ranks_of_a_host():
+    """Round 5: the host's copy rate peaks at ~16 threads in all (profiles/r5_stage_scale_*.jsonl), so a rank's input pipeline gets
+    16 // local_world staging threads (at least 2; one rank alone: 8 for fp32 staging, 16 for bf16), capped by its affinity mask;
+    RPG_STAGE_WORKERS overrides."""
+    from relpose_gnn_amd.evaluate import staging_workers as w
+    assert [w(True, k, 256, "0") for k in (1, 2, 4, 8)] == [8, 8, 4, 2]
+    assert [w(False, k, 256, "0") for k in (1, 2, 4, 8, 16)] == [16, 8, 4, 2, 2]
+    assert w(False, 1, 6, "0") == 6 and w(True, 8, 1, "0") == 1            # never more than the CPUs it may run on
+    assert w(False, 8, 256, "12") == 12 and w(False, 8, 4, "12") == 4      # explicit override, still capped
+
+
+def test_partition_for_model_built_graphs_needs_only_the_node_table():
+    """Round 5: with ``knn > 0`` the model replaces ``data.edge_index``, so the multi-stream cut needs the nodes per graph only
+    (PoseNetX_R2._graph_sizes / _partition with e_total=None) -- from this package's Batch, a PyG collation table, ``ptr`` or
+    ``batch``; host logic, no GPU."""
+    from types import SimpleNamespace
+    from relpose_gnn_amd.graph import Batch, Data, fc_edge_index
+    from relpose_gnn_amd.posenet import PoseNetX_R2
+    sizes = [8, 4, 8, 8, 4]
+    b = Batch.from_data_list([Data(x=torch.zeros(n, 12), edge_index=fc_edge_index(n)) for n in sizes])
+    gs = PoseNetX_R2._graph_sizes
+    assert gs(b, 32, None) == (sizes, [0] * 5) and gs(b, 31, None) is None
+    pyg = SimpleNamespace(x=b.x, edge_index=b.edge_index, batch=b.batch, _slice_dict={"x": torch.tensor([0, 8, 12, 20, 28, 32])})
+    assert gs(pyg, 32, None) == (sizes, [0] * 5)
+    assert gs(SimpleNamespace(x=b.x, edge_index=b.edge_index, batch=b.batch, ptr=torch.tensor([0, 8, 12, 20, 28, 32])), 32, None)[0] == sizes
+    assert gs(SimpleNamespace(x=b.x, edge_index=b.edge_index, batch=b.batch), 32, None)[0] == sizes
+    fake = SimpleNamespace(hip_streams=2, stream_schedule=None, _graph_sizes=gs)
+    parts = PoseNetX_R2._partition(fake, b, 32, None)
+    assert [(p[0], p[1], p[4]) for p in parts] == [(0, 12, 0), (12, 32, 1)]
+    fake.hip_streams = 3                                                     # 5 graphs < 2 x 3: one stream
+    assert PoseNetX_R2._partition(fake, b, 32, None) is None
