@@ -377,9 +377,16 @@ def main():
     # under a launcher (torchrun environment) the process group is RCCL at ANY world size, 1 included: the collective of
     # the step then really runs (`python bench.py --gpus 1 --launcher` is how a one-GPU box covers the N > 1 code path)
     under_launcher = "WORLD_SIZE" in os.environ
+    host_cpus = None
     if under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if world > 1:
+            # one process per GPU on a shared two-socket host: the launching thread (≈150 kernel launches per step) and whatever
+            # it allocates stay on this rank's share of the cores, on its GPU's NUMA node where sysfs names it (plain
+            # sched_setaffinity after init: no exec, no numactl hop; RPG_BIND_RANKS=0 switches it off)
+            from relpose_gnn_amd.shard import bind_rank_to_host_slice
+            host_cpus = bind_rank_to_host_slice(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), local_rank)
 
     import relpose_gnn_amd.synth as S
     from relpose_gnn_amd import ops
@@ -655,6 +662,8 @@ def main():
                                                 "sha256_12": hashlib.sha256(fh.read()).hexdigest()[:12],
                                                 "env_override": bool(os.environ.get("RPG_HIP_LIB"))}
         line["rccl_ranks_seen"] = dist.get_world_size() if under_launcher else None
+        if host_cpus is not None:
+            line["config"]["rank0_host_cpus"] = len(host_cpus)
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)

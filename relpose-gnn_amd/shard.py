@@ -68,6 +68,20 @@ def _parse_cpulist(text: str) -> List[int]:
     return out
 
 
+def gpu_numa_node(device_index: int) -> Optional[int]:
+    """NUMA node of GPU ``device_index`` per sysfs (None: unknown / -1)."""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        dom, bus, devn = getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", None), getattr(p, "pci_device_id", None)
+        if bus is None or devn is None:
+            return None
+        with open(f"/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{devn:02x}.0/numa_node") as f:
+            node = int(f.read().strip())
+        return node if node >= 0 else None
+    except Exception:
+        return None
+
+
 def gpu_local_cpus(device_index: int) -> Optional[List[int]]:
     """CPUs of the NUMA node GPU ``device_index`` hangs off, from sysfs (PCI address -> local_cpulist), or None if the
     platform does not say (no sysfs entry, numa_node = -1, virtualised PCI topology).  Never touches the GPU runtime beyond
@@ -139,14 +153,23 @@ def bind_rank_to_host_slice(local_rank: int, local_world: int, device_index: Opt
     try:
         allowed = sorted(os.sched_getaffinity(0))
         cpus = None
-        near = gpu_local_cpus(local_rank if device_index is None else device_index)
+        dev = local_rank if device_index is None else device_index
+        near = gpu_local_cpus(dev)
         if near:
             near = [c for c in near if c in set(allowed)]
-            # ranks are assumed spread evenly over the NUMA nodes (GPUs 0..W/2-1 on node 0 ...): this node's share of the ranks
-            nodes = max(1, round(len(allowed) / max(1, len(near))))
-            per_node = max(1, local_world // nodes)
+            # this rank's place among the ranks whose GPUs hang off the same NUMA node (rank r drives GPU r of this host; where
+            # a GPU's node is unknown the ranks are assumed spread evenly: GPUs 0..W/2-1 on node 0 ...)
+            my_node = gpu_numa_node(dev)
+            nodes_of = [gpu_numa_node(r) for r in range(local_world)] if (my_node is not None and dev == local_rank) else []
+            if nodes_of and all(n is not None for n in nodes_of):
+                same = [r for r, n in enumerate(nodes_of) if n == my_node]
+                per_node, place = len(same), same.index(local_rank)
+            else:
+                nodes = max(1, round(len(allowed) / max(1, len(near))))
+                per_node = max(1, local_world // nodes)
+                place = local_rank % per_node
             if near:
-                cpus = sorted(_slice_in_order(local_rank % per_node, per_node, _core_major(near)))
+                cpus = sorted(_slice_in_order(place, per_node, _core_major(near)))
         if not cpus:
             cpus = sorted(_slice_in_order(local_rank, local_world, _core_major(allowed)))
         os.sched_setaffinity(0, cpus)
