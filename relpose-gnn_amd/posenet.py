@@ -563,10 +563,13 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
                 cap = ei_buf.size(1)
                 rel = torch.empty((total, 6), dtype=torch.float32, device=dev)
                 heads(feat, n0, n1, (ei_buf.data_ptr(), ei_buf.data_ptr() + 8 * cap), 0, total, rel, slot, wkey)
-                eis.append(ei_buf[:, :total] + n0)                                # node ids of the whole batch (posenet.py:1048)
+                ei_g = ei_buf[:, :total] + n0                                     # node ids of the whole batch (posenet.py:1048)
+                eis.append(ei_g)
                 rels.append(rel)
                 for buf in (feat, ei_buf, meta):
                     buf.record_stream(st)
+                for buf in (rel, ei_g):                # allocated on the slot's stream, concatenated on the caller's below
+                    buf.record_stream(cur)
         for st in self._streams[:n_slots]:
             cur.wait_stream(st)
         self._publish_status()
