@@ -365,6 +365,9 @@ int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
                                      (49 * 2^k pixels: 3.06 / 1.53 rounds at 512 images); same arithmetic per output, bit-identical.  Bit 0 (default
                                      on): 512 x 128 -> 256 x 128 tiles (layer 2: -4..5 %); bit 1 (off): 256 x 256 -> 160 x 256 (layer 3: measured
                                      no gain); 0 = always one launch */
+#define RPG_TUNE_LIN112 29           /* fp32 Linears with a plain A operand, M % 112 == 0, N % 64 == 0, K % 32 == 0 and at least one 112 x 64 tile per CU (the
+                                     GNN's edge GEMMs: M = 56 edges x graphs = 7 * 2^k rows): 1 (default) = the exact-fit kernel on v_mfma_f32_16x16x4_f32
+                                     (no stream-K split, no fix-up launch) | 0 = the 32x32x2 tile engine */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

@@ -195,6 +195,176 @@ thread_local double t_executed = 0.0;      // FLOP the matrix pipe issues for th
 #undef RPG_ENGINE_NS
 #undef RPG_ENGINE_NT
 
+// ------------------------------------------------------------------------------------------------
+// Exact-fit Linear for M = 7 * 2^k rows (round 5).  The GNN's edge GEMMs have M = 56 edges x graphs = 1792 (32 graphs) or 896
+// (16 per stream) rows: 7 * 256 / 7 * 128 -- on 128-row tiles any equal split of the work leaves 7/8 of a power-of-two machine
+// busy, and the stream-K split that balances it costs a fix-up launch per Linear (every tiling of the 32x32x2 engine measured
+// within 4 % of 0.70 of the f32 matrix peak on the M = 1792, N = K = 2048 Linear: tools/conv_bench.py --only e).  Tiles that
+// DIVIDE it: 112 x 64 -- 16 x 32 = 512 of them for M = 1792, N = 2048: two per CU, no remainder, no split, no fix-up.  112 = 7 x 16,
+// so the fragments are those of v_mfma_f32_16x16x4_f32 (same 64 FLOP / clk / SIMD as the 32x32x2): a workgroup of 4 waves, one
+// per SIMD, wave w owning all 7 row fragments x the 16 columns 16 w .. (7 x 4 = 28 accumulator registers, + 28 of the two-level
+// sum); two workgroups per CU (51 KB of LDS each).  K advances in steps of 32 through a double-buffered LDS image [112 + 64 rows]
+// [32 + 4] as in the tile engine; a lane reads 4 consecutive k of its row at offset 4 (lane >> 4) and feeds 4 MFMAs (the same
+// k permutation for A and W).  Staging by raw buffer loads with the K position in the scalar offset (rows past 112 carry an
+// out-of-range offset), one barrier per step, every load / LDS access placed behind an MFMA.  The epilogue transposes the
+// WHOLE tile through LDS (112 x 64 floats) so that global accesses are 256-byte row segments, and finishes 16-byte column
+// groups with the engine's own code (streamk_finish_quad: bias, gathered residual rows, ReLU, second rectified output).
+// Plain A operand (one ungathered source), K % 32 == 0, N % 64 == 0, M % 112 == 0 (launcher).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+constexpr int L112_BM = 112, L112_BN = 64, L112_BK = 32, L112_LD = L112_BK + 4, L112_NT = 256;
+constexpr int L112_STAGE = (L112_BM + L112_BN) * L112_LD;                 // floats per LDS image
+constexpr int L112_SLAB = L112_BM * (L112_BN + 4);                        // floats of the epilogue slab
+constexpr int L112_LDS_BYTES = (2 * L112_STAGE > L112_SLAB ? 2 * L112_STAGE : L112_SLAB) * 4;
+int g_lin112 = 1;                    // RPG_TUNE_LIN112
+
+__global__ __launch_bounds__(L112_NT, 2) void linear112_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Wt, int ldw,
+                                                               int M, int N, int K, Epilogue ep, int tiles_n, int fold_k) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int m0 = (tile / tiles_n) * L112_BM, n0 = (tile % tiles_n) * L112_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- staging: thread (slot = tid % 8, row = tid / 8): rows row + 32 j; A rows j = 0..3 (the last pass half empty), W rows j = 0..1
+    const int slot = tid & 7, srow = tid >> 3;
+    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(A + (size_t)m0 * lda);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(Wt + (size_t)n0 * ldw);
+    unsigned aoff[4], woff[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = srow + 32 * j;
+        aoff[j] = row < L112_BM ? 4u * (unsigned)(row * lda + 4 * slot) : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) woff[j] = 4u * (unsigned)((srow + 32 * j) * ldw + 4 * slot);
+    const int st_off = srow * L112_LD + 4 * slot;
+    float4 rr[2][6];                                    // staging registers: the data of step s lives in set s & 1
+    auto load_job = [&](int set, int qj, int kpos) {    // past K: out-of-range offsets (zeros nobody uses; never an address past the matrices)
+        const bool live = kpos < K;
+        if (qj < 4) rr[set][qj] = buf_ld4(rsa, live ? aoff[qj] : OOB, 4u * (unsigned)kpos);
+        else rr[set][qj] = buf_ld4(rsw, live ? woff[qj - 4] : OOB, 4u * (unsigned)kpos);
+    };
+    auto write_job = [&](int set, int qj, int img) {
+        const int row = qj < 4 ? 32 * qj : L112_BM + 32 * (qj - 4);
+        if (qj == 3) {                                   // rows 96 .. 127: only 96 .. 111 exist in the image
+            if (srow < 16) *reinterpret_cast<float4*>(&lds[img + st_off + row * L112_LD]) = rr[set][qj];
+        } else {
+            *reinterpret_cast<float4*>(&lds[img + st_off + row * L112_LD]) = rr[set][qj];
+        }
+    };
+    // ---- fragments: lane (i16 = lane & 15, g = lane >> 4) reads 4 consecutive k at offset 4 g of row i16 (+ 16 f) / of W row 16 wave + i16
+    const int a_off = (lane & 15) * L112_LD + 4 * (lane >> 4);
+    const int b_off = (L112_BM + 16 * wave + (lane & 15)) * L112_LD + 4 * (lane >> 4);
+    float4 fa[2][7], fb[2];
+    auto read_job = [&](int set, int rj, int kb, int img) {
+        if (rj < 7) fa[set][rj] = *reinterpret_cast<const float4*>(&lds[img + a_off + rj * 16 * L112_LD + kb]);
+        else fb[set] = *reinterpret_cast<const float4*>(&lds[img + b_off + kb]);
+    };
+    auto comp = [](const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; };
+    f32x4m acc[7], acc2[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[i][e] = 0.f; acc2[i][e] = 0.f; }
+
+    // One K step t = 2 groups of 16 k = 2 x 28 MFMAs.  Behind the MFMAs of group 0: the 8 fragment reads of group 1, the 6 stage
+    // writes of step t + 1 (register set (t + 1) & 1) and, into the registers those writes just freed, the 6 loads of step t + 3
+    // -- TWO steps (~3.4 k cycles) before they are written to LDS: one step is shorter than a loaded L2 / HBM round trip, and the
+    // barrier's vmcnt(0) waited for them every step (one-step prefetch: 0.72 of the f32 matrix peak in the model, two-step: see
+    // DESIGN.md); behind group 1's: the fragment reads of the next step's group 0 from the other image.  The barrier sits after
+    // group 0: by then every wave has written image t + 1.
+    const int nsteps = K / L112_BK;
+    auto kstep = [&](int cur, int nxt, int wset, int kload) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int ms = 0; ms < 28; ++ms) {
+                const int c = ms / 7, i = ms % 7;
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(fa[g][i], c), comp(fb[g], c), acc[i], 0, 0, 0);
+                if (g == 0) {
+                    if (ms < 8) read_job(1, ms, 16, cur);
+                    else if (ms < 14) write_job(wset, ms - 8, nxt);
+                    else if (ms < 20) load_job(wset, ms - 14, kload);
+                } else {
+                    if (ms < 8) read_job(0, ms, 0, nxt);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g == 0) {
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // prologue: stage step 0, load step 1, first fragments
+#pragma unroll
+    for (int qj = 0; qj < 6; ++qj) load_job(0, qj, 0);
+#pragma unroll
+    for (int qj = 0; qj < 6; ++qj) load_job(1, qj, L112_BK);
+#pragma unroll
+    for (int qj = 0; qj < 6; ++qj) write_job(0, qj, 0);
+#pragma unroll
+    for (int qj = 0; qj < 6; ++qj) load_job(0, qj, 2 * L112_BK);
+    __syncthreads();
+#pragma unroll
+    for (int rj = 0; rj < 8; ++rj) read_job(0, rj, 0, 0);
+    const int fold_steps = fold_k >= 2 * L112_BK ? (fold_k / L112_BK) & ~1 : 0x7ffffffe;
+    int kt = 0;
+    while (kt + 1 < nsteps) {
+        int kstop = kt + fold_steps;
+        if (kstop > nsteps) kstop = nsteps;
+        for (; kt + 1 < kstop; kt += 2) {
+            kstep(0, L112_STAGE, 1, (kt + 3) * L112_BK);
+            kstep(L112_STAGE, 0, 0, (kt + 4) * L112_BK);
+        }
+        if (kt + 1 < nsteps) {
+            asm volatile("");
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { acc2[i] += acc[i]; acc[i] = f32x4m{0.f, 0.f, 0.f, 0.f}; }
+        }
+    }
+    if (kt < nsteps) kstep(0, L112_STAGE, 1, (kt + 3) * L112_BK);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc[i] += acc2[i];
+    __syncthreads();
+    // ---- epilogue: D[row = 4 (lane >> 4) + e][col = lane & 15] of fragment i -> slab [112][64 + 4]; then 16-byte column groups
+    constexpr int SP = L112_BN + 4;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[(16 * i + 4 * (lane >> 4) + e) * SP + 16 * wave + (lane & 15)] = acc[i][e];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < L112_BM * (L112_BN / 4) / L112_NT; ++t) {
+        const int idx4 = t * L112_NT + tid;
+        const int row = idx4 / (L112_BN / 4), c4 = idx4 % (L112_BN / 4);
+        const float4 v = *reinterpret_cast<const float4*>(&lds[row * SP + 4 * c4]);
+        eng4::streamk_finish_quad<L112_BM, L112_BN>(v, ep, M, N, tiles_n, tile, idx4, 1);
+    }
+}
+
+// true if launched (shape eligible)
+bool launch_linear112(const float* A, int lda, const float* Wt, int ldw, int M, int N, int K, const Epilogue& ep, hipStream_t s) {
+    if (!g_lin112 || M % L112_BM || N % L112_BN || K % L112_BK || K < 2 * L112_BK) return false;
+    const int tm = M / L112_BM, tn = N / L112_BN;
+    const long tiles = (long)tm * tn;
+    // worth it where the tiles fill the machine: >= 1 per CU (N = 2048: M = 896 -> 256 tiles, M = 1792 -> 512).  Measured below that:
+    // the attention projections' N = 768 at M = 1792 (192 tiles, one 4-wave workgroup = one wave per SIMD on three quarters of the
+    // CUs) take 79.7 us here against 75-78 us on the stream-K engine
+    if (tiles < cu_count() || (long)L112_BM * lda * 4 >= (1L << 31) || (long)L112_BN * ldw * 4 >= (1L << 31)) return false;
+    const bool vec_ok = (ep.ldc % 4 == 0) && rpg::aligned16(ep.out) && (!ep.residual || rpg::aligned16(ep.residual)) &&
+                        (!ep.residual2 || rpg::aligned16(ep.residual2)) && (ep.ldr % 4 == 0) && (!ep.scale || rpg::aligned16(ep.scale)) &&
+                        (!ep.shift || rpg::aligned16(ep.shift)) && (!ep.out_relu || rpg::aligned16(ep.out_relu)) && rpg::aligned16(A) &&
+                        rpg::aligned16(Wt) && (lda % 4 == 0) && (ldw % 4 == 0);
+    if (!vec_ok) return false;
+    t_executed = 2.0 * (double)M * N * (double)K;
+    hipLaunchKernelGGL(linear112_kernel, dim3((unsigned)tiles), dim3(L112_NT), L112_LDS_BYTES, s, A, lda, Wt, ldw, M, N, K, ep, tn, g_fold_k);
+    return true;
+}
+
 template <int BK, bool EPI, template <int, int> class Loader, class Args>
 void launch_shape(TileShape t, const Args& args, const float* Wt, int ldw, int M, int N, int K, const Epilogue& ep,
                   bool vec_ok, hipStream_t s) {
@@ -352,7 +522,8 @@ int launch_linear(const GatherSrc& src, const float* weight, const float* bias, 
         const long rows = src.idx[i] ? src.rows[i] : (long)m;          // a gathered source needs its row count
         if (rows <= 0 || rows * src.ld[i] * 4 >= (1L << 31)) seg = 0;
     }
-    launch_tiles<GatherKind, GatherArgs>(a, weight, K, m, n_out, K, ep, s, seg);
+    if (!(src.n == 1 && !src.idx[0] && launch_linear112(src.a[0], src.ld[0], weight, K, m, n_out, K, ep, s)))
+        launch_tiles<GatherKind, GatherArgs>(a, weight, K, m, n_out, K, ep, s, seg);
     timing_end(slot, 2.0 * (double)m * n_out * (double)K, s, t_executed);
     RPG_CHECK_LAUNCH("linear_gather");
     return RPG_OK;
@@ -410,6 +581,7 @@ extern "C" int rpg_set_tuning(int key, int value) {
             return RPG_OK;
         case RPG_TUNE_GNN_SPLIT: g_gnn_split = value != 0; return RPG_OK;
         case RPG_TUNE_GNN_FUSE_AGG: g_gnn_fuse_agg = value != 0; return RPG_OK;
+        case RPG_TUNE_LIN112: g_lin112 = value != 0; return RPG_OK;
         case RPG_TUNE_FOLD_K: if (value < 0 || (value % 64)) return RPG_ERR_BAD_ARG; g_fold_k = value; return RPG_OK;
         case RPG_TUNE_FAST_LOADER: g_fast = value != 0; return RPG_OK;
         case RPG_TUNE_WAVES8: g_waves8 = value != 0; return RPG_OK;

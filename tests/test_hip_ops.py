@@ -633,3 +633,33 @@ def test_streamk_partial_tiles_combined_by_last_arriver(dev, m, k, n_out, gather
     assert rel_err(y_launch.cpu(), ref) < 1e-5
     assert all(torch.equal(y, ys[0]) for y in ys[1:]), "not deterministic"
     assert rel_err(ys[0], y_launch) < 1e-6 and rel_err(ys[0].cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("m,k,n_out,res,relu", [(1792, 2048, 2048, False, True), (896, 2048, 2048, True, False), (3584, 512, 1024, True, True),
+                                                 (1792, 96, 2048, False, False), (896, 2080, 2048, False, True)])
+def test_linear_exact_fit_112_row_tiles(dev, m, k, n_out, res, relu):
+    """Round 5: Linears with M = 7 * 2^k rows (the GNN's edge GEMMs: 56 edges x graphs) on 112 x 64 tiles of
+    v_mfma_f32_16x16x4_f32 -- no stream-K split, no fix-up launch (RPG_TUNE_LIN112 = 1, csrc/gemm_f32.hip linear112_kernel;
+    reference op: nn.Linear of my_gnn_layer.py:236-239,304-311).  Against F.linear on the CPU (1e-5 like every fp32 op test)
+    and against the 32x32x2 tile engine on the same operands (= 0): K % 32 tails that are not a multiple of the fold length,
+    K = 96 (three steps: odd step count), residual rows, ReLU, 1 / 2 / 4 tiles per CU."""
+    from relpose_gnn_amd import ops
+    a = _rand(m, k, seed=31)
+    wt = _rand(n_out, k, seed=32, scale=k ** -0.5)
+    bias = _rand(n_out, seed=33, scale=0.1)
+    ref = F.linear(a, wt, bias)
+    r = None
+    if res:
+        r = _rand(m, n_out, seed=34)
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    outs = {}
+    try:
+        for mode in (1, 0):
+            ops.set_tuning(ops.TUNE_LIN112, mode)
+            outs[mode] = ops.linear_gather([(a.to(dev), None)], wt.to(dev), bias.to(dev), m, None if r is None else r.to(dev), relu).cpu()
+    finally:
+        ops.set_tuning(ops.TUNE_LIN112, 1)
+    assert rel_err(outs[1], ref) < TOL and rel_err(outs[0], ref) < TOL, (rel_err(outs[1], ref), rel_err(outs[0], ref))
+    assert rel_err(outs[1], outs[0]) < TOL
