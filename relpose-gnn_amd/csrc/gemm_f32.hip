@@ -216,7 +216,7 @@ constexpr int L112_BM = 112, L112_BN = 64, L112_BK = 32, L112_LD = L112_BK + 4, 
 constexpr int L112_STAGE = (L112_BM + L112_BN) * L112_LD;                 // floats per LDS image
 constexpr int L112_SLAB = L112_BM * (L112_BN + 4);                        // floats of the epilogue slab
 constexpr int L112_LDS_BYTES = (2 * L112_STAGE > L112_SLAB ? 2 * L112_STAGE : L112_SLAB) * 4;
-int g_lin112 = 1;                    // RPG_TUNE_LIN112
+int g_lin112 = 3;                    // RPG_TUNE_LIN112: bit 0 the exact-fit kernel, bit 1 its eight-wave form for launches of about one tile per CU
 
 __global__ __launch_bounds__(L112_NT, 2) void linear112_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Wt, int ldw,
                                                                int M, int N, int K, Epilogue ep, int tiles_n, int fold_k) {
@@ -346,9 +346,134 @@ __global__ __launch_bounds__(L112_NT, 2) void linear112_kernel(const float* __re
     }
 }
 
+// The same tile on EIGHT waves for launches with about one tile per CU (M = 896: the default two-stream schedule's edge GEMMs):
+// with one 4-wave workgroup per CU every SIMD holds a lone wave, nothing hides its barrier and LDS latencies (measured: ~0.62 of
+// the matrix rate inside the K loop against ~0.8 with two waves per SIMD).  Waves 0..3 take the first 16 k of every 32-deep step,
+// waves 4..7 the second 16 (same column blocks); the two partial tiles meet in the LDS slab in front of the epilogue (waves 4..7
+// first, then 0..3 add theirs: (k 0..15 + k 32..47 + ...) + (k 16..31 + ...) -- a summation order of its own, like every tiling).
+constexpr int L112_NT2 = 512;
+__global__ __launch_bounds__(L112_NT2, 1) void linear112k2_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Wt, int ldw,
+                                                                 int M, int N, int K, Epilogue ep, int tiles_n, int fold_k) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int m0 = (tile / tiles_n) * L112_BM, n0 = (tile % tiles_n) * L112_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kw = wave >> 2, wv = wave & 3;                 // k half of a step / column block of this wave
+    // staging: thread (slot = tid % 8, row = tid / 8 in 0..63): A rows row, row + 64 (>= 112: nothing), W row `row`
+    const int slot = tid & 7, srow = tid >> 3;
+    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(A + (size_t)m0 * lda);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(Wt + (size_t)n0 * ldw);
+    unsigned soff[3];
+    soff[0] = 4u * (unsigned)(srow * lda + 4 * slot);
+    soff[1] = srow + 64 < L112_BM ? 4u * (unsigned)((srow + 64) * lda + 4 * slot) : OOB;
+    soff[2] = 4u * (unsigned)(srow * ldw + 4 * slot);
+    const int st_off = srow * L112_LD + 4 * slot;
+    float4 rr[2][3];
+    auto load_job = [&](int set, int qj, int kpos) {
+        const bool live = kpos < K;
+        rr[set][qj] = buf_ld4(qj < 2 ? rsa : rsw, live ? soff[qj] : OOB, 4u * (unsigned)kpos);
+    };
+    auto write_job = [&](int set, int qj, int img) {
+        const int row = qj == 0 ? 0 : (qj == 1 ? 64 : L112_BM);
+        if (qj == 1) {
+            if (srow + 64 < L112_BM) *reinterpret_cast<float4*>(&lds[img + st_off + row * L112_LD]) = rr[set][qj];
+        } else {
+            *reinterpret_cast<float4*>(&lds[img + st_off + row * L112_LD]) = rr[set][qj];
+        }
+    };
+    const int a_off = (lane & 15) * L112_LD + 4 * (lane >> 4) + 16 * kw;
+    const int b_off = (L112_BM + 16 * wv + (lane & 15)) * L112_LD + 4 * (lane >> 4) + 16 * kw;
+    float4 fa[2][7], fb[2];
+    auto read_job = [&](int set, int rj, int img) {
+        if (rj < 7) fa[set][rj] = *reinterpret_cast<const float4*>(&lds[img + a_off + rj * 16 * L112_LD]);
+        else fb[set] = *reinterpret_cast<const float4*>(&lds[img + b_off]);
+    };
+    auto comp = [](const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; };
+    f32x4m acc[7], acc2[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[i][e] = 0.f; acc2[i][e] = 0.f; }
+    // step t: 28 MFMAs per wave on fragment set t & 1; behind them the 3 stage writes of step t + 1 and the 3 loads of step t + 3,
+    // then the barrier, then the 8 fragment reads of step t + 1 from the image just completed
+    const int nsteps = K / L112_BK;
+    auto kstep = [&](int fset, int nxt, int wset, int kload) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ms = 0; ms < 28; ++ms) {
+            const int c = ms / 7, i = ms % 7;
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp(fa[fset][i], c), comp(fb[fset], c), acc[i], 0, 0, 0);
+            if (ms < 3) write_job(wset, ms, nxt);
+            else if (ms < 6) load_job(wset, ms - 3, kload);
+            else if (ms >= 14 && ms < 22) read_job(fset ^ 1, ms - 14, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ms == 13) {
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+#pragma unroll
+    for (int qj = 0; qj < 3; ++qj) load_job(0, qj, 0);
+#pragma unroll
+    for (int qj = 0; qj < 3; ++qj) load_job(1, qj, L112_BK);
+#pragma unroll
+    for (int qj = 0; qj < 3; ++qj) write_job(0, qj, 0);
+#pragma unroll
+    for (int qj = 0; qj < 3; ++qj) load_job(0, qj, 2 * L112_BK);
+    __syncthreads();
+#pragma unroll
+    for (int rj = 0; rj < 8; ++rj) read_job(0, rj, 0);
+    const int fold_steps = fold_k >= 2 * L112_BK ? (fold_k / L112_BK) & ~1 : 0x7ffffffe;
+    int kt = 0;
+    while (kt + 1 < nsteps) {
+        int kstop = kt + fold_steps;
+        if (kstop > nsteps) kstop = nsteps;
+        for (; kt + 1 < kstop; kt += 2) {
+            kstep(0, L112_STAGE, 1, (kt + 3) * L112_BK);
+            kstep(1, 0, 0, (kt + 4) * L112_BK);
+        }
+        if (kt + 1 < nsteps) {
+            asm volatile("");
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { acc2[i] += acc[i]; acc[i] = f32x4m{0.f, 0.f, 0.f, 0.f}; }
+        }
+    }
+    if (kt < nsteps) kstep(0, L112_STAGE, 1, (kt + 3) * L112_BK);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc[i] += acc2[i];
+    __syncthreads();
+    constexpr int SP = L112_BN + 4;
+    if (kw == 1) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lds[(16 * i + 4 * (lane >> 4) + e) * SP + 16 * wv + (lane & 15)] = acc[i][e];
+    }
+    __syncthreads();
+    if (kw == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float* p = &lds[(16 * i + 4 * (lane >> 4) + e) * SP + 16 * wv + (lane & 15)];
+                *p = acc[i][e] + *p;
+            }
+    }
+    __syncthreads();
+    for (int idx4 = tid; idx4 < L112_BM * (L112_BN / 4); idx4 += L112_NT2) {
+        const int row = idx4 / (L112_BN / 4), c4 = idx4 % (L112_BN / 4);
+        const float4 v = *reinterpret_cast<const float4*>(&lds[row * SP + 4 * c4]);
+        eng4::streamk_finish_quad<L112_BM, L112_BN>(v, ep, M, N, tiles_n, tile, idx4, 1);
+    }
+}
+
 // true if launched (shape eligible)
 bool launch_linear112(const float* A, int lda, const float* Wt, int ldw, int M, int N, int K, const Epilogue& ep, hipStream_t s) {
-    if (!g_lin112 || M % L112_BM || N % L112_BN || K % L112_BK || K < 2 * L112_BK) return false;
+    if (!(g_lin112 & 1) || M % L112_BM || N % L112_BN || K % L112_BK || K < 2 * L112_BK) return false;
     const int tm = M / L112_BM, tn = N / L112_BN;
     const long tiles = (long)tm * tn;
     // worth it where the tiles fill the machine: >= 1 per CU (N = 2048: M = 896 -> 256 tiles, M = 1792 -> 512).  Measured below that:
@@ -361,7 +486,11 @@ bool launch_linear112(const float* A, int lda, const float* Wt, int ldw, int M, 
                         rpg::aligned16(Wt) && (lda % 4 == 0) && (ldw % 4 == 0);
     if (!vec_ok) return false;
     t_executed = 2.0 * (double)M * N * (double)K;
-    hipLaunchKernelGGL(linear112_kernel, dim3((unsigned)tiles), dim3(L112_NT), L112_LDS_BYTES, s, A, lda, Wt, ldw, M, N, K, ep, tn, g_fold_k);
+    // about one tile per CU: eight waves per tile (two per SIMD); from two tiles per CU on: four waves, two workgroups per CU
+    if ((g_lin112 & 2) && 2 * tiles < 3L * cu_count())
+        hipLaunchKernelGGL(linear112k2_kernel, dim3((unsigned)tiles), dim3(L112_NT2), L112_LDS_BYTES, s, A, lda, Wt, ldw, M, N, K, ep, tn, g_fold_k);
+    else
+        hipLaunchKernelGGL(linear112_kernel, dim3((unsigned)tiles), dim3(L112_NT), L112_LDS_BYTES, s, A, lda, Wt, ldw, M, N, K, ep, tn, g_fold_k);
     return true;
 }
 
@@ -581,7 +710,7 @@ extern "C" int rpg_set_tuning(int key, int value) {
             return RPG_OK;
         case RPG_TUNE_GNN_SPLIT: g_gnn_split = value != 0; return RPG_OK;
         case RPG_TUNE_GNN_FUSE_AGG: g_gnn_fuse_agg = value != 0; return RPG_OK;
-        case RPG_TUNE_LIN112: g_lin112 = value != 0; return RPG_OK;
+        case RPG_TUNE_LIN112: if (value < 0 || value > 3) return RPG_ERR_BAD_ARG; g_lin112 = value; return RPG_OK;
         case RPG_TUNE_FOLD_K: if (value < 0 || (value % 64)) return RPG_ERR_BAD_ARG; g_fold_k = value; return RPG_OK;
         case RPG_TUNE_FAST_LOADER: g_fast = value != 0; return RPG_OK;
         case RPG_TUNE_WAVES8: g_waves8 = value != 0; return RPG_OK;

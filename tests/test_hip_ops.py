@@ -656,10 +656,11 @@ def test_linear_exact_fit_112_row_tiles(dev, m, k, n_out, res, relu):
         ref = F.relu(ref)
     outs = {}
     try:
-        for mode in (1, 0):
+        for mode in (3, 1, 0):                               # eight-wave form where about one tile per CU / four-wave form only / engine
             ops.set_tuning(ops.TUNE_LIN112, mode)
             outs[mode] = ops.linear_gather([(a.to(dev), None)], wt.to(dev), bias.to(dev), m, None if r is None else r.to(dev), relu).cpu()
     finally:
-        ops.set_tuning(ops.TUNE_LIN112, 1)
-    assert rel_err(outs[1], ref) < TOL and rel_err(outs[0], ref) < TOL, (rel_err(outs[1], ref), rel_err(outs[0], ref))
-    assert rel_err(outs[1], outs[0]) < TOL
+        ops.set_tuning(ops.TUNE_LIN112, 3)
+    for mode in (3, 1, 0):
+        assert rel_err(outs[mode], ref) < TOL, (mode, rel_err(outs[mode], ref))
+    assert rel_err(outs[1], outs[0]) < TOL and rel_err(outs[3], outs[0]) < TOL

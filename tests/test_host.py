@@ -47,7 +47,7 @@ def test_tuning_and_timer_constants_match_the_header():
     assert lib.rpg_set_tuning(defs["RPG_TUNE_BK"], 24) == _lib.RPG_ERR_BAD_ARG
     assert lib.rpg_set_tuning(defs["RPG_TUNE_WINOGRAD"], 7) == _lib.RPG_ERR_BAD_ARG
     for name, key in tune.items():                                    # defaults are accepted and restore the defaults
-        default = {"TILE": -1, "BK": 0, "BF16_BK": 32, "WINO_SHORT": 0, "BF16_TILE": -1, "BF16_WS64": 0, "SK_MIN_ITS": 8, "INKERNEL_FIXUP": 0, "BF16_CHUNK": 0, "WINO2D": 0, "BF16_LINEAR_DMA": 0, "BF16_PERSIST": 0, "FOLD_K": 256}.get(name, 1)
+        default = {"TILE": -1, "BK": 0, "BF16_BK": 32, "WINO_SHORT": 0, "BF16_TILE": -1, "BF16_WS64": 0, "SK_MIN_ITS": 8, "INKERNEL_FIXUP": 0, "BF16_CHUNK": 0, "WINO2D": 0, "BF16_LINEAR_DMA": 0, "BF16_PERSIST": 0, "FOLD_K": 256, "LIN112": 3}.get(name, 1)
         assert lib.rpg_set_tuning(key, default) == 0, name
     # the weights-stationary probe kernel is not part of the product library (tools/probes/conv3x3_bf16_ws64.inc)
     assert lib.rpg_set_tuning(defs["RPG_TUNE_BF16_WS64"], 1) == _lib.RPG_ERR_BAD_ARG
