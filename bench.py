@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 BF16_MATRIX_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA (MI355X_MICROARCH.md)
@@ -282,6 +283,50 @@ def other_configs(model, args, dev):
         out["latency_1graph_256x341"] = {"ms": round(1e3 * sorted(ts)[len(ts) // 2], 4), "graphs_per_s": round(1.0 / sorted(ts)[len(ts) // 2], 1),
                                          "what": "one 8-node 256x341 graph per forward + .cpu() of the relative poses per call (median of 30): "
                                                  "what INTEGRATION.md's 3-line edit of testing/test.py yields per iteration, fp32"}
+        # the reference's loop AS WRITTEN (batch_size = 1 loader, model(data.to(device)), .cpu().data.numpy() per graph:
+        # test.py:205-251) over relpose_gnn_amd.lookahead: the loader is read 64 graphs ahead and the forwards are batched
+        from relpose_gnn_amd.graph import Batch
+        from relpose_gnn_amd.lookahead import lookahead
+        items = [Batch.from_data_list([Data(x=px, edge_index=ei8, y=py)]) for px, py in pool]     # what DataLoader(batch_size=1) collates
+
+        class _Loader:
+            batch_size = 1
+
+            def __init__(self, n):
+                self.n = n
+
+            def __len__(self):
+                return self.n
+
+            def __iter__(self):
+                return (items[i % len(items)] for i in range(self.n))
+
+        def ref_loop(n):
+            loader, wrapped = lookahead(_Loader(n), model, dev, micro_batch=mb)
+            preds = []
+            for batch_idx, data in enumerate(loader):
+                output, output_R, edge_index = wrapped(data.to(dev))
+                s = output.size()
+                output_R = output_R.cpu().data.numpy().reshape((-1, s[-1]))
+                target = data.y.to("cpu").numpy().reshape((-1, s[-1]))
+                edges = edge_index.cpu().data.numpy()
+                preds.append(E.query_pose(output_R, target, edges, np.zeros(3), np.ones(3), 0)[0])
+            return np.stack(preds), wrapped
+
+        ref_loop(2 * mb)
+        torch.cuda.synchronize()
+        n = 1024
+        t0 = time.perf_counter()
+        preds, wrapped = ref_loop(n)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert preds.shape == (n, 7) and bool((preds == preds).all()) and wrapped.direct_calls == 0
+        out["reference_loop_lookahead_256x341"] = {
+            "value": round(n / dt, 1), "unit": "graphs/s", "seconds": round(dt, 3), "graphs": n, "forwards": wrapped.forwards, "dtype": "f32",
+            "what": "testing/test.py:205-251 as written (one graph per iteration from a batch_size=1 loader in pageable host memory, "
+                    "model(data.to(device)), .cpu().data.numpy(), query pose per graph) with the loader and the module wrapped by "
+                    f"relpose_gnn_amd.lookahead.lookahead(loader, model, device, micro_batch={mb}); the same loop on the bare module: "
+                    "latency_1graph_256x341"}
     finally:
         model.encoder_dtype, model.gnn_dtype, model.hip_streams, model.input_img_height = "f32", "f32", args.streams, IMG
     return out
@@ -645,6 +690,8 @@ def main():
                     sec[short] = [v.get("value"), v.get("ms_per_step", v.get("seconds")), (v.get("roofline") or {}).get("frac")]
             if isinstance(others.get("latency_1graph_256x341"), dict):
                 sec["lat1_256x341_ms"] = others["latency_1graph_256x341"]["ms"]
+            if isinstance(others.get("reference_loop_lookahead_256x341"), dict):       # test.py's own loop over lookahead(): graphs/s
+                sec["c3_ref_loop_lookahead"] = others["reference_loop_lookahead_256x341"]["value"]
             if "error" in others:
                 sec["error"] = others["error"]
             if lat1 is not None:

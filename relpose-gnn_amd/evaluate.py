@@ -207,6 +207,78 @@ def _collate_on_device(chunk: Sequence[Data], x_dev: torch.Tensor, device) -> Ba
     return out
 
 
+class _MicroBatchRunner:
+    """Launch side of the evaluation pipeline, shared by ``evaluate_stream`` and ``lookahead.Lookahead``: collate a chunk of
+    single-graph ``Data`` objects (through the pinned double buffers of ``_InputPipeline`` when the images live on the host
+    and the model on the GPU), run ONE forward over it and start the asynchronous copy of the poses (and of a model-built
+    edge list) into pinned host memory.  ``launch`` returns without waiting; ``item.ev`` marks the poses' arrival."""
+
+    def __init__(self, model, device, micro_batch: int, h2d_dtype=torch.float32, local_world: int = 1, want_abs: bool = False):
+        self.model, self.device, self.micro_batch = model, device, int(micro_batch)
+        self.h2d_dtype, self.local_world, self.want_abs = h2d_dtype, local_world, want_abs
+        self.on_gpu = torch.device(device).type == "cuda"
+        self.pipe: Optional[_InputPipeline] = None
+        self.n_batches = 0
+        self.h2d_bytes = 0
+
+    def launch(self, chunk: Sequence[Data]):
+        """-> (chunk, host_rel, host_ei | None, ev | None, host_abs | None, x_dev): x_dev = the chunk's node images as the
+        forward read them (rows in chunk order)."""
+        device, model = self.device, self.model
+        k = self.n_batches & 1
+        self.n_batches += 1
+        staged = self.on_gpu and not any(g.x.is_cuda for g in chunk)
+        if staged:
+            rows, width = sum(g.x.shape[0] for g in chunk), int(chunk[0].x.shape[1])
+            if self.pipe is None or not self.pipe.fits(rows, width, self.h2d_dtype):
+                if self.pipe is not None:
+                    torch.cuda.synchronize(device)                  # a larger buffer pair replaces one that is in flight
+                cap = max(rows, max(g.x.shape[0] for g in chunk) * self.micro_batch)
+                self.pipe = _InputPipeline(torch.device(device), cap, width, self.h2d_dtype, self.local_world)
+            x_dev = self.pipe.stage(k, chunk)
+            self.h2d_bytes += x_dev.numel() * x_dev.element_size()
+            batch = _collate_on_device(chunk, x_dev, device)
+            self.pipe.acquire(k)
+        else:
+            if self.on_gpu and not all(g.x.is_cuda for g in chunk):
+                # a chunk that mixes device- and host-resident graphs (ADVICE r3): the host ones go over one by one, the
+                # collation then happens on the device (torch.cat would refuse mixed devices)
+                batch = Batch.from_data_list([g.to(device, non_blocking=True) for g in chunk])
+            else:
+                batch = Batch.from_data_list(chunk).to(device, non_blocking=True)
+        ab, rel, edge_index = model(batch)
+        if staged:
+            self.pipe.release(k)
+        # a model-built edge list (kNN graph: the reference's default --knn 4, test.py:308, posenet.py:1047-1048) comes
+        # back instead of the stored one: it travels to the host with the poses and is cut per graph by the consumer
+        model_built = edge_index is not batch.edge_index
+        host_abs = None
+        if self.on_gpu:
+            host = torch.empty(rel.shape, dtype=rel.dtype, pin_memory=True)
+            host.copy_(rel, non_blocking=True)
+            if self.want_abs:
+                host_abs = torch.empty(ab.shape, dtype=ab.dtype, pin_memory=True)
+                host_abs.copy_(ab, non_blocking=True)
+            host_ei = None
+            if model_built:
+                host_ei = torch.empty(edge_index.shape, dtype=edge_index.dtype, pin_memory=True)
+                host_ei.copy_(edge_index, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, host_ei, ev = rel, (edge_index if model_built else None), None
+            host_abs = ab if self.want_abs else None
+        return chunk, host, host_ei, ev, host_abs, batch.x
+
+
+def edges_per_graph(ei: np.ndarray, sizes: Sequence[int]):
+    """Cut a model-built edge list [2, E] of a collated micro-batch at graph boundaries: -> (first node of every graph,
+    [column indices of graph k]); the batch order of the columns is kept (test.py:227 takes the FIRST edge into the node)."""
+    first = np.concatenate([[0], np.cumsum(np.asarray(sizes))])
+    gid = np.searchsorted(first, ei[1], side="right") - 1              # graph of every edge (by its target node)
+    return first, [np.flatnonzero(gid == k) for k in range(len(sizes))]
+
+
 @torch.no_grad()
 def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64, pose_m=(0.0, 0.0, 0.0),
                     pose_s=(1.0, 1.0, 1.0), ref_node: int = 0, rank: int = 0, world: int = 1,
@@ -225,69 +297,25 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
     pose_m, pose_s = np.asarray(pose_m, dtype=np.float64), np.asarray(pose_s, dtype=np.float64)
     local_world = 1
     if world > 1 and torch.device(device).type == "cuda":
-        import os as _os
-        local_world = int(_os.environ.get("LOCAL_WORLD_SIZE", world))
+        import os
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
         # one process per GPU on a shared host: this rank's staging threads and pinned buffers stay on its share of the
         # cores / its GPU's NUMA node (shard.bind_rank_to_host_slice; RPG_BIND_RANKS=0 switches it off).  LOCAL_* from the
         # launcher when it set them (ranks of other nodes do not share this host)
-        import os
         bind_rank_to_host_slice(int(os.environ.get("LOCAL_RANK", rank)), int(os.environ.get("LOCAL_WORLD_SIZE", world)),
                                 torch.device(device).index)
     lo, hi = shard_range(len(graphs), rank, world)
-    on_gpu = torch.device(device).type == "cuda"
     preds: List[np.ndarray] = []
     targs: List[np.ndarray] = []
-    pipe: Optional[_InputPipeline] = None
-    n_batches = 0
-    h2d_bytes = 0
     # the bf16 encoder takes its node images in bf16 (rounded while they are staged: half the H2D bytes, identical results)
     h2d_dtype = torch.bfloat16 if (bf16_input if bf16_input is not None else getattr(model, "accepts_bf16_input", False)) else torch.float32
+    runner = _MicroBatchRunner(model, device, micro_batch, h2d_dtype, local_world)
 
     def launch(b0):
-        nonlocal pipe, n_batches, h2d_bytes
-        chunk = [graphs[i] for i in range(b0, min(hi, b0 + micro_batch))]
-        k = n_batches & 1
-        n_batches += 1
-        staged = on_gpu and not any(g.x.is_cuda for g in chunk)
-        if staged:
-            rows, width = sum(g.x.shape[0] for g in chunk), int(chunk[0].x.shape[1])
-            if pipe is None or not pipe.fits(rows, width, h2d_dtype):
-                if pipe is not None:
-                    torch.cuda.synchronize(device)                  # a larger buffer pair replaces one that is in flight
-                cap = max(rows, max(g.x.shape[0] for g in chunk) * micro_batch)
-                pipe = _InputPipeline(torch.device(device), cap, width, h2d_dtype, local_world)
-            x_dev = pipe.stage(k, chunk)
-            h2d_bytes += x_dev.numel() * x_dev.element_size()
-            batch = _collate_on_device(chunk, x_dev, device)
-            pipe.acquire(k)
-        else:
-            if on_gpu and not all(g.x.is_cuda for g in chunk):
-                # a chunk that mixes device- and host-resident graphs: the host ones go over one by one, the
-                # collation then happens on the device (torch.cat would refuse mixed devices)
-                batch = Batch.from_data_list([g.to(device, non_blocking=True) for g in chunk])
-            else:
-                batch = Batch.from_data_list(chunk).to(device, non_blocking=True)
-        _, rel, edge_index = model(batch)
-        if staged:
-            pipe.release(k)
-        # a model-built edge list (kNN graph: the reference's default --knn 4, test.py:308, posenet.py:1047-1048) comes
-        # back instead of the stored one: it travels to the host with the poses and is cut per graph in finish()
-        model_built = edge_index is not batch.edge_index
-        if on_gpu:
-            host = torch.empty(rel.shape, dtype=rel.dtype, pin_memory=True)
-            host.copy_(rel, non_blocking=True)
-            host_ei = None
-            if model_built:
-                host_ei = torch.empty(edge_index.shape, dtype=edge_index.dtype, pin_memory=True)
-                host_ei.copy_(edge_index, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-        else:
-            host, host_ei, ev = rel, (edge_index if model_built else None), None
-        return chunk, host, host_ei, ev
+        return runner.launch([graphs[i] for i in range(b0, min(hi, b0 + micro_batch))])
 
     def finish(item):
-        chunk, host, host_ei, ev = item
+        chunk, host, host_ei, ev = item[:4]
         if ev is not None:
             ev.synchronize()
         check = getattr(model, "check_edge_index", None)
@@ -296,11 +324,9 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
         rel = host.numpy()
         if host_ei is not None:
             ei = host_ei.numpy()
-            sizes = np.asarray([g.num_nodes for g in chunk])
-            first = np.concatenate([[0], np.cumsum(sizes)])
-            gid = np.searchsorted(first, ei[1], side="right") - 1          # graph of every edge (by its target node)
+            first, per_graph = edges_per_graph(ei, [g.num_nodes for g in chunk])
             for k, g in enumerate(chunk):
-                cols = np.flatnonzero(gid == k)                            # batch order kept: test.py takes the FIRST hit
+                cols = per_graph[k]
                 p, t = query_pose(rel[cols], g.y.cpu().numpy(), ei[:, cols] - first[k], pose_m, pose_s, ref_node)
                 preds.append(p)
                 targs.append(t)
@@ -324,8 +350,8 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
     if getattr(model, "check_edge_index", None) is not None:
         model.check_edge_index()                       # everything has been issued: wait for the last report
     if stats is not None:
-        stats["h2d_bytes"] = h2d_bytes
-        stats["micro_batches"] = n_batches
+        stats["h2d_bytes"] = runner.h2d_bytes
+        stats["micro_batches"] = runner.n_batches
     pred = np.stack(preds) if preds else np.zeros((0, 7))
     targ = np.stack(targs) if targs else np.zeros((0, 7))
     import torch.distributed as dist

@@ -249,3 +249,75 @@ def test_partition_for_model_built_graphs_needs_only_the_node_table():
     assert [(p[0], p[1], p[4]) for p in parts] == [(0, 12, 0), (12, 32, 1)]
     fake.hip_streams = 3                                                     # 5 graphs < 2 x 3: one stream
     assert PoseNetX_R2._partition(fake, b, 32, None) is None
+
+
+class _StubLoader:
+    """DataLoader(batch_size=1) stand-in: yields single-graph batches, has __len__ / batch_size / dataset (test.py:193,205-207)."""
+    batch_size = 1
+
+    def __init__(self, graphs):
+        from relpose_gnn_amd.graph import Batch
+        self.dataset, self._batch, self.reads = graphs, Batch, 0
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __iter__(self):
+        for g in self.dataset:
+            self.reads += 1
+            yield self._batch.from_data_list([g])
+
+
+class _StubModel:
+    """(abs, rel, edge_index) as a per-node function of the images: any batching gives the same rows."""
+    index_check = "deferred"
+
+    def __init__(self, knn=False):
+        self.calls, self.knn = [], knn
+
+    def __call__(self, data, k=None):
+        f = data.x.reshape(data.x.shape[0], -1).float().mean(1, keepdim=True)
+        ab = f * torch.arange(1, 7, dtype=torch.float32)
+        ei = data.edge_index
+        if self.knn:                                         # a model-built edge list: every stored edge reversed, new tensor
+            ei = torch.stack([data.edge_index[1], data.edge_index[0]])
+        self.calls.append(int(data.x.shape[0]))
+        return ab, ab[ei[1]] - ab[ei[0]], ei
+
+
+@pytest.mark.parametrize("knn", [False, True])
+def test_lookahead_keeps_the_reference_loop_and_batches_the_forwards(knn):
+    """relpose_gnn_amd.lookahead: the loop of test.py:205-251 unchanged (enumerate(loader), len(loader), loader.batch_size,
+    len(data), model(data.to(device)), .cpu().data.numpy()) over 11 graphs of 8 / 5 nodes with micro_batch = 4 issues three
+    forwards (4 + 4 + 3 graphs), reads the loader one micro-batch ahead, and gives every iteration the rows the module returns
+    for that graph alone."""
+    from relpose_gnn_amd.lookahead import lookahead
+    g = torch.Generator().manual_seed(3)
+    graphs = [Data(x=torch.randn(n, 3 * 6 * 8, generator=g), edge_index=fc_edge_index(n), y=torch.randn(n, 6, generator=g), edge_attr=None)
+              for n in (8, 5, 8, 8, 5, 8, 8, 8, 5, 8, 8)]
+    base, model = _StubLoader(graphs), _StubModel(knn)
+    loader, wrapped = lookahead(base, model, "cpu", micro_batch=4)
+    assert len(loader) == 11 and loader.batch_size == 1 and loader.dataset is graphs and wrapped.index_check == "deferred"
+    alone = _StubModel(knn)
+    seen = 0
+    for batch_idx, data in enumerate(loader):
+        assert batch_idx == seen and len(data) == 1
+        if batch_idx == 0:
+            assert base.reads == 8                            # two micro-batches have been read before the first graph comes out
+        output, output_R, edge_index = wrapped(data.to("cpu"))
+        s = output.size()
+        want = alone(_StubLoader([graphs[batch_idx]])._batch.from_data_list([graphs[batch_idx]]))
+        assert s == want[0].size() and torch.equal(data.y, graphs[batch_idx].y) and torch.equal(data.x, graphs[batch_idx].x)
+        assert np.array_equal(output.cpu().data.numpy(), want[0].numpy())
+        assert np.array_equal(output_R.cpu().data.numpy().reshape((-1, s[-1])), want[1].numpy())
+        assert np.array_equal(edge_index.cpu().data.numpy(), want[2].numpy())
+        seen += 1
+    assert seen == 11 and model.calls == [29, 29, 21] and wrapped.forwards == 3 and wrapped.direct_calls == 0
+    # anything that is not the graph just handed out goes to the module itself
+    extra = _StubLoader(graphs)._batch.from_data_list(graphs[:2])
+    out = wrapped(extra)
+    assert wrapped.direct_calls == 1 and model.calls[-1] == 13 and out[0].shape == (13, 6)
+    wrapped.index_check = "sync"                              # attribute writes reach the module
+    assert model.index_check == "sync"
+    with pytest.raises(ValueError):                           # a loader with more than one graph per item is not the reference's loop
+        list(lookahead([extra], model, "cpu")[0])

@@ -694,6 +694,66 @@ def test_reference_eval_loop_as_written_batch_size_1(dev):
     assert np.allclose(pred_poses, np.stack(want), atol=2e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("knn", [-1, 4])
+def test_reference_eval_loop_through_lookahead(dev, knn):
+    """relpose_gnn_amd.lookahead: the loop of test.py:205-251 literally, once over the plain loader and module
+    (one forward per graph) and once over ``lookahead(loader, model, device, micro_batch=4)`` (three forwards for 10 graphs,
+    images through the pinned staging pipeline, host tensors back) -- the same predicted and target poses.  knn = 4: the
+    module builds the edge list (posenet.py:1047-1048) and the adapter cuts it per graph."""
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd import evaluate as E
+    from relpose_gnn_amd.graph import Batch, Data, fc_edge_index
+    from relpose_gnn_amd.lookahead import lookahead
+    from relpose_gnn_amd.posenet import PoseNetX_R2
+    from relpose_gnn_amd.resnet import ResNet
+    planes, blocks, D = (8, 16, 32, 64), (1, 1, 1, 1), 64
+    m = PoseNetX_R2(ResNet(blocks, planes), droprate=0.0, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D,
+                    input_img_height=32, use_gnn=True, knn=knn, use_AP=True, gnn_recursion=2)
+    m.load_state_dict(S.synth_state_dict(S.posenet_r2_param_shapes(D, D, D, planes, blocks), seed=1))
+    m = m.to(dev).eval()
+    pose_m, pose_s = np.array([0.5, -1.0, 2.0]), np.array([2.0, 3.0, 0.5])
+    graphs = [Data(x=S.synth_images(8, 32, 40, seed=600 + i), edge_index=fc_edge_index(8), y=S.hash_normal(f"la.y{i}", (8, 6), 0.3),
+                   edge_attr=None) for i in range(10)]
+
+    class Loader:                                            # DataLoader(data_set, batch_size=1, shuffle=False) of test.py:193
+        batch_size = 1
+
+        def __len__(self):
+            return len(graphs)
+
+        def __iter__(self):
+            return (Batch.from_data_list([g]) for g in graphs)
+
+    def reference_loop(loader, model):                       # test.py:205-251
+        pred_poses, targ_poses, batch_size, ref_node = [], [], 1, 0
+        for batch_idx, data in enumerate(loader):
+            batch_size_ = min(len(data), loader.batch_size)
+            output, output_R, edge_index = model(data.to(dev))
+            s = output.size()
+            output_R = output_R.cpu().data.numpy().reshape((-1, s[-1]))
+            target = data.y.to("cpu").numpy().reshape((-1, s[-1]))
+            edges = edge_index.cpu().data.numpy()
+            ref_idx = np.argwhere(edges[1] == 0)[ref_node, 0]
+            out = np.expand_dims(target[edges[0, ref_idx], :] - output_R[ref_idx, :], axis=0)
+            out = np.hstack((out[:, :3], np.asarray(tuple(E.qexp(p[3:]) for p in out))))
+            target = np.hstack((target[:, :3], np.asarray(tuple(E.qexp(p[3:]) for p in target))))
+            out[:, :3] = out[:, :3] * pose_s + pose_m
+            target[:, :3] = target[:, :3] * pose_s + pose_m
+            for j in range(batch_size_):
+                pred_poses.append(out[0])
+                targ_poses.append(target[0])
+                assert len(pred_poses) == batch_idx * batch_size + j + 1
+        return np.array(pred_poses), np.array(targ_poses)
+
+    plain_p, plain_t = reference_loop(Loader(), m)
+    loader, wrapped = lookahead(Loader(), m, dev, micro_batch=4)
+    ahead_p, ahead_t = reference_loop(loader, wrapped)
+    assert wrapped.forwards == 3 and wrapped.direct_calls == 0 and ahead_p.shape == (10, 7)
+    assert np.allclose(ahead_p, plain_p, atol=2e-5) and np.array_equal(ahead_t, plain_t)
+    res = E.evaluate_stream(m, graphs, dev, micro_batch=4, pose_m=pose_m, pose_s=pose_s)
+    assert np.allclose(ahead_p, res.pred_poses, atol=5e-6)   # the same micro-batches through the same pipeline
+
+
 def test_foreign_torchvision_style_feature_extractor(dev):
     """any module with torchvision's ResNet attribute layout works as ``feature_extractor`` -- only its
     ``state_dict()`` (torchvision's key names), ``.avgpool`` and ``.fc.in_features`` are read (posenet.py:942-945).  Here a
