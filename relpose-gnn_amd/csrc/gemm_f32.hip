@@ -174,6 +174,10 @@ inline TileShape pick_tile(int M, int N, int K) {
     if (g_force_tile >= 0 && g_force_tile <= 3) return (TileShape)g_force_tile;
     if (N <= 64) return (M >= 256 * 256) ? TILE_256x64 : TILE_64x64;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    // a K loop of <= 16 steps is all prologue and epilogue: small tiles, several workgroups per CU hiding each other's (the 1x1 / stride 2
+    // downsample convolutions, r5, tools/conv_bench.py --only ds --tile t: K = 64 / 128 / 256: 64.9 / 55.4 / 49.0 us on 128x128 tiles,
+    // 55.7 / 48.7 / 47.0 on 64x64)
+    if (K <= 256 && t128 >= 384) return TILE_64x64;
     if (t128 >= 384) return TILE_128x128;                 // >= 1.5 big tiles per CU
     // fewer big tiles than CUs can balance: fine with stream-K when K is long enough to split, else go small
     // (128x64 halves the tile so that twice as many workgroups share the work before stream-K has to split K: measured
