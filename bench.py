@@ -29,6 +29,11 @@ import os
 import sys
 import time
 
+# RCCL shares device buffers between the ranks' processes through HIP IPC handles and the pool's host driver only supports
+# the dmabuf flavour: without this the first collective of a multi-rank run fails with "hipIpcGetMemHandle: invalid
+# argument".  Already exported on the GPU boxes; set here too (before the HIP runtime starts) for any other launcher.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

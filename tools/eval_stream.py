@@ -19,6 +19,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL (bench.py explains); before the HIP runtime starts
+
 import numpy as np
 import torch
 
