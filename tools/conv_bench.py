@@ -35,6 +35,15 @@ LINEAR = [  # name, m, widths, n_out
     ("attW", 1792, (256,), 2048),
     ("upd0", 256, (2048, 2048), 2048),
     ("fc", 256, (512,), 2048),
+    # the per-NODE GEMMs of the split formulation (forward.hip node_gemm): M = nodes
+    ("nd.projn", 256, (2048,), 4096),
+    ("nd.node3", 256, (2048,), 6144),
+    ("nd.upd2", 256, (2048,), 2048),
+    ("nd.attW", 256, (256,), 2048),
+    ("nd128.projn", 128, (2048,), 4096),
+    ("nd128.node3", 128, (2048,), 6144),
+    ("nd128.upd0", 128, (2048, 2048), 2048),
+    ("nd128.upd2", 128, (2048,), 2048),
 ]
 
 
