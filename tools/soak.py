@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Soak / determinism run on the GPU box: the same inputs through every scheduling variant of the module, over and over, for
+--seconds; every repetition must reproduce the first result of its variant BIT FOR BIT (the multi-stream forward, the
+stream-K / split-K fix-ups and the two-phase kNN path are all deterministic by construction: no atomics on data, fixed
+summation orders).  Variants: two streams / one stream (fp32), knn = 4 on two streams, bf16 encoder + bf16 GNN, the
+evaluation stream and the reference loop over lookahead() (same micro-batches: equal to each other).
+    python tools/soak.py --seconds 240"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import relpose_gnn_amd.synth as S  # noqa: E402
+from relpose_gnn_amd import evaluate as E  # noqa: E402
+from relpose_gnn_amd.graph import Batch, Data, fc_batch, fc_edge_index  # noqa: E402
+from relpose_gnn_amd.lookahead import lookahead  # noqa: E402
+from relpose_gnn_amd.posenet import PoseNetX_R2  # noqa: E402
+from relpose_gnn_amd.resnet import resnet34  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--graphs", type=int, default=16)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    D, H, W = 2048, 224, 224
+    sd = S.synth_state_dict(S.posenet_r2_param_shapes(D, D, D), seed=1)
+
+    def build(knn):
+        m = PoseNetX_R2(resnet34(), droprate=0.0, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D, input_img_height=H,
+                        use_gnn=True, knn=knn, use_AP=True, gnn_recursion=2)
+        m.load_state_dict(sd)
+        return m.to(dev).eval()
+
+    fc, kn = build(-1), build(4)
+    x = torch.randn((8 * args.graphs, 3 * H * W), generator=torch.Generator(device=dev).manual_seed(9), device=dev)
+    data = fc_batch(x, 8)
+    gen = torch.Generator().manual_seed(10)
+    host_graphs = [Data(x=torch.randn((8, 3 * H * W), generator=gen), edge_index=fc_edge_index(8), y=torch.randn((8, 6), generator=gen) * 0.3)
+                   for _ in range(24)]
+
+    class Loader:
+        batch_size = 1
+
+        def __len__(self):
+            return len(host_graphs)
+
+        def __iter__(self):
+            return (Batch.from_data_list([g]) for g in host_graphs)
+
+    def ref_loop(model):
+        loader, wrapped = lookahead(Loader(), model, dev, micro_batch=8)
+        out = []
+        for data_ in loader:
+            o, o_r, ei = wrapped(data_.to(dev))
+            out.append(E.query_pose(o_r.cpu().data.numpy().astype(np.float64), data_.y.numpy().astype(np.float64), ei.cpu().data.numpy(),
+                                    np.zeros(3), np.ones(3), 0)[0])
+        return torch.from_numpy(np.stack(out))
+
+    def run(model, streams, enc="f32", gnn="f32"):
+        model.hip_streams, model.encoder_dtype, model.gnn_dtype = streams, enc, gnn
+        a, r, ei = model(data)
+        return torch.cat([a.flatten(), r.flatten(), ei.flatten().float()])
+
+    variants = {
+        "fp32_2streams": lambda: run(fc, 2),
+        "fp32_1stream": lambda: run(fc, 1),
+        "knn4_2streams": lambda: run(kn, 2),
+        "bf16_all_2streams": lambda: run(fc, 2, "bf16", "bf16"),
+        "eval_stream": lambda: (setattr(fc, "hip_streams", 2), setattr(fc, "encoder_dtype", "f32"), setattr(fc, "gnn_dtype", "f32"),
+                                torch.from_numpy(E.evaluate_stream(fc, host_graphs, dev, micro_batch=8).pred_poses))[-1],
+        "ref_loop_lookahead": lambda: (setattr(fc, "hip_streams", 2), setattr(fc, "encoder_dtype", "f32"), setattr(fc, "gnn_dtype", "f32"),
+                                       ref_loop(fc))[-1],
+    }
+    first, reps, bad = {}, {k: 0 for k in variants}, {k: 0 for k in variants}
+    t_end = time.time() + args.seconds
+    while time.time() < t_end:
+        for name, fn in variants.items():
+            out = fn()
+            torch.cuda.synchronize()
+            out = out.detach().cpu()
+            assert bool(torch.isfinite(out).all()), name
+            if name not in first:
+                first[name] = out.clone()
+            elif not torch.equal(out, first[name]):
+                bad[name] += 1
+            reps[name] += 1
+    close = float((first["eval_stream"] - first["ref_loop_lookahead"]).abs().max())
+    rec = {"seconds": args.seconds, "graphs_per_forward": args.graphs, "repetitions": reps, "bitwise_mismatches": bad,
+           "eval_stream_vs_ref_loop_max_abs": close}
+    print(json.dumps(rec))
+    sys.exit(1 if any(bad.values()) or close > 1e-5 else 0)
+
+
+if __name__ == "__main__":
+    main()
