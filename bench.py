@@ -255,24 +255,39 @@ def other_configs(model, args, dev):
         gen = torch.Generator().manual_seed(77)
         ei8 = fc_edge_index(NODES)
         pool = [(torch.randn((NODES, 3 * h * w), generator=gen), torch.randn((NODES, 6), generator=gen) * 0.3) for _ in range(64)]
+        # The reference's loader delivers PINNED tensors (DataLoader(..., pin_memory=True), testing/test.py:193): that is the primary
+        # stream number; the same stream out of pageable memory (a plain loader) is reported next to it.
+        pinned_pool = [(px.pin_memory(), py) for px, py in pool]
         for name, dt_name, n in (("configs3_eval_stream_1gpu_host_fp32", "f32", 2000), ("configs4_eval_stream_1gpu_host_bf16", "bf16", 4000)):
             model.encoder_dtype = model.gnn_dtype = dt_name
-            graphs = [Data(x=pool[i % len(pool)][0], edge_index=ei8, y=pool[i % len(pool)][1]) for i in range(n)]
-            E.evaluate_stream(model, graphs[:2 * mb], dev, micro_batch=mb)              # warm-up: packing, workspaces, staging buffers
-            torch.cuda.synchronize()
-            stats = {}
-            t0 = time.perf_counter()
-            res = E.evaluate_stream(model, graphs, dev, micro_batch=mb, stats=stats)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            assert res.pred_poses.shape == (n, 7) and bool((res.pred_poses == res.pred_poses).all())
-            out[name] = {"value": round(n / dt, 1), "unit": "graphs/s", "seconds": round(dt, 3), "graphs": n,
+            legs = {}
+            for leg, src, bfin in (("pinned", pinned_pool, None), ("pageable", pool, None)) + ((("pinned_f32_h2d", pinned_pool, False),) if dt_name == "bf16" else ()):
+                graphs = [Data(x=src[i % len(src)][0], edge_index=ei8, y=src[i % len(src)][1]) for i in range(n)]
+                E.evaluate_stream(model, graphs[:2 * mb], dev, micro_batch=mb, bf16_input=bfin)   # warm-up: packing, workspaces, staging buffers
+                torch.cuda.synchronize()
+                stats = {}
+                t0 = time.perf_counter()
+                res = E.evaluate_stream(model, graphs, dev, micro_batch=mb, stats=stats, bf16_input=bfin)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                assert res.pred_poses.shape == (n, 7) and bool((res.pred_poses == res.pred_poses).all())
+                legs[leg] = {"value": round(n / dt, 1), "seconds": round(dt, 3), "h2d_gb_per_s": round(stats.get("h2d_bytes", 0) / dt / 1e9, 2),
+                             "staged_gb": round(stats.get("staged_bytes", 0) / 1e9, 3), "direct_gb": round(stats.get("direct_bytes", 0) / 1e9, 3),
+                             "staging_workers": stats.get("staging_workers")}
+                del graphs
+            prim = legs["pinned"]
+            out[name] = {"value": prim["value"], "unit": "graphs/s", "seconds": prim["seconds"], "graphs": n, "input": "pinned",
                          "dtype": "f32" if dt_name == "f32" else "bf16 encoder + bf16 GNN Linears (f32 accumulate), images staged as bf16",
-                         "h2d_gb_per_s": round(stats.get("h2d_bytes", 0) / dt / 1e9, 2),
+                         "h2d_gb_per_s": prim["h2d_gb_per_s"], "legs": legs,
                          "workload": f"BASELINE.json configs[{3 if dt_name == 'f32' else 4}] shape on ONE GPU: {n} 8-node FC graphs of {h}x{w} synthetic "
-                                     f"images in pageable host memory -> evaluate_stream (micro-batch {mb}, pinned double-buffered H2D on a "
-                                     "copy stream, D2H + test.py:213-251 post-processing per graph included); the 4- / 8-GPU sharding is "
-                                     "tools/eval_stream.py under torch.distributed.run"}
+                                     f"images in PINNED host memory (the reference's DataLoader(pin_memory=True), test.py:193) -> evaluate_stream "
+                                     f"(micro-batch {mb}, H2D on a copy stream"
+                                     + (": fp32 sources go straight from the loader's pinned tensors, no staging copy" if dt_name == "f32" else
+                                        ": the fp32 sources are rounded to bf16 by the staging threads on the way, half the H2D bytes; leg "
+                                        "pinned_f32_h2d sends them as they are")
+                                     + ", D2H + test.py:213-251 post-processing per graph included); legs.pageable = the same stream out of "
+                                     "pageable memory; the 4- / 8-GPU sharding is tools/eval_stream.py under torch.distributed.run"}
+        del pinned_pool
         # single graph at the evaluation shape (what the unmodified testing/test.py:192-211 loop feeds: batch_size=1, 8 x 256x341)
         model.encoder_dtype = model.gnn_dtype = "f32"
         d1 = fc_batch(torch.randn((NODES, 3 * h * w), generator=torch.Generator(device=dev).manual_seed(5), device=dev), NODES)
@@ -569,10 +584,22 @@ def main():
             ref_flags = reference_default_flags(model_factory, args, dev, x, 1e3 * elapsed / args.steps)
         except Exception as exc:
             ref_flags = {"error": f"{type(exc).__name__}: {exc}"}
+    from relpose_gnn_amd.shard import rank_report
+    report = rank_report(dev, elapsed, args.steps, None if host_cpus is None else len(host_cpus))     # collective: every rank
+    allgather_ms = None
     if under_launcher:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the step's one collective on its own: 20 all-gathers of the rel poses back to back (latency-bound: 43 KB per rank)
+        rel0 = out[:B].contiguous() if out.shape[0] >= B else out
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            gather_rows(rel0, counts, always=True)
+        torch.cuda.synchronize()
+        allgather_ms = round(1e3 * (time.perf_counter() - t0) / 20, 4)
     assert out.shape[-1] == 6 and bool(torch.isfinite(out).all())
 
     if rank == 0:
@@ -686,36 +713,53 @@ def main():
                                                     "per call with a host synchronisation after each / per call when 40 calls are streamed")
         if others is not None:
             line["other_configs"] = others
-            # compact copy INSIDE `config` (the driver's record keeps `config` whole): [graphs/s, ms per step | seconds, roofline frac]
-            sec = {}
-            for short, key in (("c2_bf16enc", "configs2_bf16_encoder"), ("c2_bf16all", "configs2_bf16_all"),
-                               ("c3_stream_fp32", "configs3_eval_stream_1gpu_host_fp32"), ("c4_stream_bf16", "configs4_eval_stream_1gpu_host_bf16")):
+            # FLAT scalar copies inside `config` (the driver's record keeps the scalar values of `config`, not nested objects:
+            # VERDICT r5 item 2); the nested forms stay under `other_configs` / `reference_default_flags`
+            cfg = line["config"]
+            for short, key in (("c2_bf16enc", "configs2_bf16_encoder"), ("c2_bf16all", "configs2_bf16_all")):
                 v = others.get(key)
                 if isinstance(v, dict):
-                    sec[short] = [v.get("value"), v.get("ms_per_step", v.get("seconds")), (v.get("roofline") or {}).get("frac")]
+                    cfg[short + "_gps"] = v.get("value")
+                    cfg[short + "_ms"] = v.get("ms_per_step")
+                    cfg[short + "_frac"] = (v.get("roofline") or {}).get("frac")
+            for short, key in (("c3_stream_fp32", "configs3_eval_stream_1gpu_host_fp32"), ("c4_stream_bf16", "configs4_eval_stream_1gpu_host_bf16")):
+                v = others.get(key)
+                if isinstance(v, dict):
+                    cfg[short + "_gps"] = v.get("value")                    # pinned sources (the reference's loader)
+                    for leg, lv in (v.get("legs") or {}).items():
+                        if leg != "pinned":
+                            cfg[f"{short}_{leg}_gps"] = lv.get("value")
+                    cfg[short + "_pinned_staged_gb"] = ((v.get("legs") or {}).get("pinned") or {}).get("staged_gb")
             if isinstance(others.get("latency_1graph_256x341"), dict):
-                sec["lat1_256x341_ms"] = others["latency_1graph_256x341"]["ms"]
+                cfg["lat1_256x341_ms"] = others["latency_1graph_256x341"]["ms"]
             if isinstance(others.get("reference_loop_lookahead_256x341"), dict):       # test.py's own loop over lookahead(): graphs/s
-                sec["c3_ref_loop_lookahead"] = others["reference_loop_lookahead_256x341"]["value"]
+                cfg["c3_ref_loop_lookahead_gps"] = others["reference_loop_lookahead_256x341"]["value"]
             if "error" in others:
-                sec["error"] = others["error"]
-            if lat1 is not None:
-                sec["lat1_ms"] = lat1["latency_1graph_ms"]
-            if isinstance(ref_flags, dict):
-                for kk, v in ref_flags.items():
-                    sec["c1_" + kk] = [v.get("value"), v.get("ms_per_step"), v.get("over_headline_step")] if isinstance(v, dict) else v
-            line["config"]["secondary"] = sec
+                cfg["secondary_error"] = str(others["error"])[:120]
+        if lat1 is not None:
+            line["config"]["lat1_ms"] = lat1["latency_1graph_ms"]
+        if isinstance(ref_flags, dict):
+            for kk, v in ref_flags.items():
+                if isinstance(v, dict):
+                    line["config"]["c1_" + kk.replace(".", "") + "_gps"] = v.get("value")
+                else:
+                    line["config"]["c1_flags_error"] = str(v)[:120]
         if ref_flags is not None:
             line["reference_default_flags"] = ref_flags
         import hashlib
         from relpose_gnn_amd import _lib as _L
         with open(_L.LIB_PATH, "rb") as fh:
-            line["config"]["loaded_library"] = {"path": os.path.relpath(_L.LIB_PATH, ROOT) if _L.LIB_PATH.startswith(ROOT) else _L.LIB_PATH,
-                                                "sha256_12": hashlib.sha256(fh.read()).hexdigest()[:12],
-                                                "env_override": bool(os.environ.get("RPG_HIP_LIB"))}
-        line["rccl_ranks_seen"] = dist.get_world_size() if under_launcher else None
-        if host_cpus is not None:
-            line["config"]["rank0_host_cpus"] = len(host_cpus)
+            lib_sha = hashlib.sha256(fh.read()).hexdigest()[:12]
+        lib_rel = os.path.relpath(_L.LIB_PATH, ROOT) if _L.LIB_PATH.startswith(ROOT) else _L.LIB_PATH
+        line["config"]["loaded_library"] = f"{lib_rel}@{lib_sha}" + (" (RPG_HIP_LIB override)" if os.environ.get("RPG_HIP_LIB") else "")
+        # what the collectives themselves observed (shard.rank_report): flat scalars, so a < 7x result at 8 GPUs can be attributed
+        # to a rank (slowest_rank, rank_ms_spread), a socket (numa_nodes_seen, host_cpus_*), a launcher mistake (distinct_gpus <
+        # ranks) or the collective (allgather_ms against ms_per_step)
+        line["rccl_ranks_seen"] = report["rccl_ranks_seen"]
+        for kk, v in report.items():
+            line["config"][kk] = v
+        if allgather_ms is not None:
+            line["config"]["allgather_ms"] = allgather_ms
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)

@@ -194,6 +194,22 @@ int rpg_linear_gather_f32(int n_src, const float* const* a, const int64_t* const
                           const int* width, const float* weight, const float* bias, const float* residual,
                           float* out, int m, int n_out, int relu, void* stream);
 
+/* The same Linear with the epilogue the composite GNN forward uses for the split formulation of the concatenated-input
+ * Linears (W [x_a, x_b, e] = W_a x_a + W_b x_b + W_e e, node terms computed once per node; my_gnn_layer.py:236-239,304-311
+ * -- the reference materialises the torch.cat): the residual rows may be GATHERED,
+ *   out[r] = act( cat_k(a_k[idx_k[r]]) W^T + bias + residual[(res_idx ? res_idx[r] : r) * ldr + :]
+ *                                                 + residual2[res2_idx[r] * ldr + :] ),
+ * and out_relu (or NULL) receives max(out, 0) as a second tensor of the same shape (the caller-side ReLU of
+ * posenet.py:1064-1065 next to the un-activated value).  rows[k]: row count of a gathered source k (its index range; 0 /
+ * NULL for plain sources); ldr >= n_out: row pitch of residual / residual2 (floats); res_idx == NULL and residual2 == NULL
+ * = rpg_linear_gather_f32 (ldr 0 or n_out); residual2 needs res_idx AND res2_idx.  RPG_ERR_BAD_ARG: residual2 without both
+ * index arrays, index arrays without residual, ldr < n_out, mis-aligned out_relu.                                        */
+int rpg_linear_gather_ex_f32(int n_src, const float* const* a, const int64_t* const* idx, const int* ld,
+                             const int* width, const long* rows, const float* weight, const float* bias,
+                             const float* residual, const int64_t* res_idx, const float* residual2,
+                             const int64_t* res2_idx, int ldr, float* out, float* out_relu, int m, int n_out, int relu,
+                             void* stream);
+
 /* AttentionBlock core (att.py:20-31) on rows: gtp [r][3c] = [g | theta | phi] projections,
  * y[r][i] = sum_j softmax_j(phi_i * theta_j) * g_j.                                            */
 int rpg_attention_rows_f32(const float* gtp, int r, int c, float* y, void* stream);

@@ -27,7 +27,7 @@ SYMBOLS = (
     "rpg_resnet_forward_bf16", "rpg_gnn_forward_bf16", "rpg_f32_to_bf16", "rpg_linear_bf16",
     "rpg_release_scratch", "rpg_timing_read_ex", "rpg_stem_conv7x7s2_bn_relu_maxpool_f32", "rpg_stem_pair_table",
     "rpg_attention_aggregate_f32", "rpg_stem_conv7x7s2_bn_relu_maxpool_bf16", "rpg_stem_conv7x7s2_bn_relu_maxpool_bf16_xbf16",
-    "rpg_resnet_forward_bf16_xbf16", "rpg_host_f32_to_bf16", "rpg_basicblock64_bf16",
+    "rpg_resnet_forward_bf16_xbf16", "rpg_host_f32_to_bf16", "rpg_basicblock64_bf16", "rpg_linear_gather_ex_f32",
 )
 
 
@@ -58,6 +58,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.rpg_edge_concat_gather_f32.argtypes = [_vp, _vp, _i, _i, _vp, _vp]
     lib.rpg_linear_gather_f32.argtypes = [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), _vp, _vp,
                                           _vp, _vp, _i, _i, _i, _vp]
+    lib.rpg_linear_gather_ex_f32.argtypes = [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_long),
+                                             _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]
     lib.rpg_attention_rows_f32.argtypes = [_vp, _i, _i, _vp, _vp]
     lib.rpg_scatter_mean_f32.argtypes = [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]
     lib.rpg_attention_aggregate_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]

@@ -686,6 +686,28 @@ extern "C" int rpg_linear_gather_f32(int n_src, const float* const* a, const int
     return rpg::launch_linear(src, weight, bias, residual, out, m, n_out, relu, rpg::as_stream(stream));
 }
 
+extern "C" int rpg_linear_gather_ex_f32(int n_src, const float* const* a, const int64_t* const* idx, const int* ld,
+                                        const int* width, const long* rows, const float* weight, const float* bias,
+                                        const float* residual, const int64_t* res_idx, const float* residual2,
+                                        const int64_t* res2_idx, int ldr, float* out, float* out_relu, int m, int n_out,
+                                        int relu, void* stream) {
+    if (n_src < 1 || n_src > 3 || !a || !ld || !width) return RPG_ERR_BAD_ARG;
+    rpg::GatherSrc src{};
+    src.n = n_src;
+    for (int i = 0; i < n_src; ++i) {
+        src.a[i] = a[i];
+        src.idx[i] = idx ? idx[i] : nullptr;
+        src.ld[i] = ld[i];
+        src.width[i] = width[i];
+        src.rows[i] = rows ? rows[i] : 0;
+    }
+    if (!res_idx && !residual2)          // plain residual rows (pitch n_out), as rpg_linear_gather_f32
+        return (res2_idx || (residual && ldr && ldr != n_out)) ? RPG_ERR_BAD_ARG
+               : rpg::launch_linear(src, weight, bias, residual, out, m, n_out, relu, rpg::as_stream(stream), nullptr, out_relu);
+    rpg::GatherRes gr{residual, res_idx, residual2, res2_idx, ldr};
+    return rpg::launch_linear(src, weight, bias, nullptr, out, m, n_out, relu, rpg::as_stream(stream), &gr, out_relu);
+}
+
 extern "C" int rpg_release_scratch(void) {
     if (hipDeviceSynchronize() != hipSuccess) {
         rpg::set_last_error("release_scratch", hipGetLastError());

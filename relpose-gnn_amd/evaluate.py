@@ -125,6 +125,8 @@ class _InputPipeline:
         self.sent = [torch.cuda.Event() for _ in range(2)]
         self.used = [torch.cuda.Event() for _ in range(2)]
         self.n_sent = [0, 0]
+        self.staged_bytes = 0       # pageable -> pinned through the staging threads
+        self.direct_bytes = 0       # sent straight out of the caller's own pinned tensors (no staging copy)
 
     def fits(self, rows: int, row_floats: int, dtype=torch.float32) -> bool:
         return rows <= self.host[0].shape[0] and row_floats == self.host[0].shape[1] and dtype == self.dtype
@@ -140,8 +142,10 @@ class _InputPipeline:
             n = g.x.shape[0]
             if g.x.is_pinned() and g.x.dtype == self.dtype:
                 direct.append((off, n, g.x))
+                self.direct_bytes += g.x.numel() * g.x.element_size()
             else:
                 jobs.append((off, n, g.x))
+                self.staged_bytes += g.x.numel() * host.element_size()
             off += n
         if jobs:
             # pageable -> pinned by a few worker threads (numpy releases the GIL; one memcpy stream moves ~5 GB/s on the GPU
@@ -291,19 +295,26 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
     device are collated there instead), and once both are enqueued the host post-processes micro-batch i-1, whose relative
     poses have come back through an asynchronous copy -- so neither the H2D transfer of the images (537 MB per 64 graphs
     at 256x341), nor the D2H of the poses, nor the numpy work of test.py:213-251 leaves the GPU idle.
-    ``stats`` (optional dict) receives ``h2d_bytes`` (bytes sent through the staging pipeline) and ``micro_batches``.  ``bf16_input`` (default: whatever the model
+    ``stats`` (optional dict) receives ``h2d_bytes`` (bytes sent through the input pipeline), ``staged_bytes`` (of those: copied pageable -> pinned
+    by the staging threads), ``direct_bytes`` (sent straight out of the caller's pinned tensors), ``staging_workers``, ``micro_batches`` and
+    ``local_seconds`` (this rank's block, before the all-gather).  ``bf16_input`` (default: whatever the model
     accepts, i.e. True for the bf16 encoder with its fused stem): host-resident images are rounded to bf16 while they are staged."""
-    from .shard import bind_rank_to_host_slice, gather_rows, shard_counts, shard_range
-    pose_m, pose_s = np.asarray(pose_m, dtype=np.float64), np.asarray(pose_s, dtype=np.float64)
-    local_world = 1
+    from .shard import rank_host_slice
     if world > 1 and torch.device(device).type == "cuda":
         import os
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
         # one process per GPU on a shared host: this rank's staging threads and pinned buffers stay on its share of the
-        # cores / its GPU's NUMA node (shard.bind_rank_to_host_slice; RPG_BIND_RANKS=0 switches it off).  LOCAL_* from the
-        # launcher when it set them (ranks of other nodes do not share this host)
-        bind_rank_to_host_slice(int(os.environ.get("LOCAL_RANK", rank)), int(os.environ.get("LOCAL_WORLD_SIZE", world)),
-                                torch.device(device).index)
+        # cores / its GPU's NUMA node for the duration of the call (shard.rank_host_slice puts the caller's mask back on
+        # return; a process its entry script has bound already is left as it is; RPG_BIND_RANKS=0 switches it off).  LOCAL_*
+        # from the launcher when it set them (ranks of other nodes do not share this host)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        with rank_host_slice(int(os.environ.get("LOCAL_RANK", rank)), local_world, torch.device(device).index):
+            return _evaluate_stream(model, graphs, device, micro_batch, pose_m, pose_s, ref_node, rank, world, stats, bf16_input, local_world)
+    return _evaluate_stream(model, graphs, device, micro_batch, pose_m, pose_s, ref_node, rank, world, stats, bf16_input, 1)
+
+
+def _evaluate_stream(model, graphs, device, micro_batch, pose_m, pose_s, ref_node, rank, world, stats, bf16_input, local_world):
+    from .shard import gather_rows, shard_counts, shard_range
+    pose_m, pose_s = np.asarray(pose_m, dtype=np.float64), np.asarray(pose_s, dtype=np.float64)
     lo, hi = shard_range(len(graphs), rank, world)
     preds: List[np.ndarray] = []
     targs: List[np.ndarray] = []
@@ -339,6 +350,8 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
             targs.append(t)
             e0 += e
 
+    import time
+    t_local = time.perf_counter()
     pending = None
     for b0 in range(lo, hi, micro_batch):
         item = launch(b0)
@@ -350,12 +363,23 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
     if getattr(model, "check_edge_index", None) is not None:
         model.check_edge_index()                       # everything has been issued: wait for the last report
     if stats is not None:
+        stats["local_seconds"] = time.perf_counter() - t_local      # this rank's own block, before the all-gather
         stats["h2d_bytes"] = runner.h2d_bytes
         stats["micro_batches"] = runner.n_batches
+        pipe = runner.pipe
+        # bytes that went pageable -> pinned through the staging threads / straight out of the caller's own pinned tensors
+        stats["staged_bytes"] = pipe.staged_bytes if pipe is not None else 0
+        stats["direct_bytes"] = pipe.direct_bytes if pipe is not None else 0
+        stats["staging_workers"] = pipe.workers if pipe is not None else 0
     pred = np.stack(preds) if preds else np.zeros((0, 7))
     targ = np.stack(targs) if targs else np.zeros((0, 7))
     import torch.distributed as dist
-    if world > 1 or (dist.is_available() and dist.is_initialized() and dist.get_world_size() == world):
+    grouped = dist.is_available() and dist.is_initialized() and dist.get_world_size() == world
+    if grouped and world == 1:
+        # world size 1: only where the group's backend can take this device's tensors (an NCCL group cannot all-gather the CPU
+        # tensors of a device="cpu" run -- ADVICE r5; before round 5 world = 1 never reached a collective)
+        grouped = torch.device(device).type == "cuda" or dist.get_backend() != "nccl"
+    if world > 1 or grouped:
         # under a process group the collective runs at ANY world size, 1 included: a one-GPU box then executes the same RCCL
         # all-gather the 4- / 8-GPU stream does (tools/eval_stream.py under torch.distributed.run)
         both = torch.from_numpy(np.concatenate([pred, targ], 1)).to(device)

@@ -71,6 +71,9 @@ class Lookahead:
         self.__dict__["_stream"] = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self.__dict__["forwards"] = 0        # batched forwards issued (tests / statistics)
         self.__dict__["direct_calls"] = 0    # calls that went to the module itself
+        self.__dict__["_direct_pending"] = False   # a direct call ran on the caller's stream since the last batched launch
+        self.__dict__["_in_loop"] = False    # the wrapped loader is being iterated
+        self.__dict__["_warned"] = False
 
     def __getattr__(self, name):
         return getattr(self.__dict__["_model"], name)
@@ -90,8 +93,18 @@ class Lookahead:
             self.__dict__["_expect"] = None
             return exp[1]
         self.__dict__["direct_calls"] += 1
+        if self._in_loop and exp is not None and k is None and not self._warned:
+            # inside the wrapped loop, with a graph on offer, and the call did not present it: most likely the caller cloned /
+            # re-laid-out data.x (the ticket is recognised by the device address of x).  Correct, but every such call is a
+            # whole single-graph forward -- say so once instead of silently running at a third of the rate.
+            import warnings
+            warnings.warn("lookahead: model(data) inside the wrapped loop was not given the graph the loader just yielded (data.x is "
+                          "a different tensor: cloned / reshaped into new memory?) -- running a separate forward for it; the batched "
+                          "result of that graph is discarded", RuntimeWarning, stacklevel=2)
+            self.__dict__["_warned"] = True
         if self._stream is not None:         # the module's workspaces are shared: a direct call waits for the forwards in flight
             torch.cuda.current_stream().wait_stream(self._stream)
+            self.__dict__["_direct_pending"] = True     # ... and the next batched launch waits for this one (start())
         return self._model(data, k) if k is not None else self._model(data)
 
     # ---- the generator behind the wrapped loader ---------------------------------------------------------------
@@ -122,11 +135,26 @@ class Lookahead:
             graphs = [self._as_graph(d) for d in items]
             if self._stream is None:
                 return items, runner.launch(graphs)
+            if self._direct_pending:
+                # a direct forward was enqueued on the caller's stream after the last batched launch: it uses the module's
+                # default workspaces, which the next batched forward may share (hip_streams = 1, small micro-batches) -- order
+                # the two in THIS direction too (the other direction is the wait in __call__)
+                self._stream.wait_stream(torch.cuda.current_stream())
+                self.__dict__["_direct_pending"] = False
             with torch.cuda.stream(self._stream):
                 return items, runner.launch(graphs)
 
         if self._stream is not None:         # whatever the caller enqueued so far (weights, a direct forward) comes first
             self._stream.wait_stream(torch.cuda.current_stream())
+            self.__dict__["_direct_pending"] = False
+        self.__dict__["_in_loop"] = True
+        try:
+            yield from self._drain(start)
+        finally:
+            self.__dict__["_in_loop"] = False
+            self.__dict__["_expect"] = None
+
+    def _drain(self, start):
         cur = start()
         while cur is not None:
             nxt = start()                    # micro-batch i + 1 is staged and enqueued before micro-batch i is handed out

@@ -295,6 +295,46 @@ def linear_gather(sources: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]]
     return out
 
 
+def linear_gather_ex(sources: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]], weight: torch.Tensor, bias: Optional[torch.Tensor],
+                     m: int, residual: Optional[torch.Tensor] = None, res_idx: Optional[torch.Tensor] = None,
+                     residual2: Optional[torch.Tensor] = None, res2_idx: Optional[torch.Tensor] = None, relu: bool = False,
+                     want_relu_copy: bool = False, widths: Optional[Sequence[int]] = None):
+    """rpg_linear_gather_ex_f32: linear_gather with gathered residual rows, an optional max(out, 0) copy and A operands that are
+    column blocks of wider tensors (``widths[k]`` < a_k.shape[1]: row pitch a_k.shape[1], the first widths[k] columns are read).
+    -> out, or (out, out_relu) with ``want_relu_copy``."""
+    ns = len(sources)
+    keep = [(_req(a, f"a{i}"), None if ix is None else _req(ix, f"idx{i}", torch.int64)) for i, (a, ix) in enumerate(sources)]
+    wd_l = [a.shape[1] for a, _ in keep] if widths is None else [int(v) for v in widths]
+    if len(wd_l) != ns or any(w <= 0 or w > a.shape[1] for w, (a, _) in zip(wd_l, keep)):
+        raise ValueError("widths: one positive entry per source, at most the source's row pitch")
+    weight = _req(weight, "weight")
+    bias = None if bias is None else _req(bias, "bias")
+    residual = None if residual is None else _req(residual, "residual")
+    residual2 = None if residual2 is None else _req(residual2, "residual2")
+    res_idx = None if res_idx is None else _req(res_idx, "res_idx", torch.int64)
+    res2_idx = None if res2_idx is None else _req(res2_idx, "res2_idx", torch.int64)
+    n_out = weight.shape[0]
+    if sum(wd_l) != weight.shape[1]:
+        raise ValueError("sum of source widths != weight.shape[1]")
+    for r_, i_ in ((residual, res_idx), (residual2, res2_idx)):
+        if r_ is not None and (r_.shape[1] < n_out or (i_ is None and r_.shape[0] != m) or (i_ is not None and i_.numel() != m)):
+            raise ValueError("residual: [rows][>= n_out] with one (gathered) row per output row")
+    if residual is not None and residual2 is not None and residual.shape[1] != residual2.shape[1]:
+        raise ValueError("residual and residual2 share one row pitch")
+    out = torch.empty((m, n_out), dtype=torch.float32, device=weight.device)
+    out_relu = torch.empty_like(out) if want_relu_copy else None
+    a_arr = L.ptr_array([a.data_ptr() for a, _ in keep])
+    i_arr = L.ptr_array([None if ix is None else ix.data_ptr() for _, ix in keep])
+    ld = L.int_array([a.shape[1] for a, _ in keep])
+    wd = L.int_array(wd_l)
+    import ctypes as C
+    rows = (C.c_long * ns)(*[a.shape[0] if ix is not None else 0 for a, ix in keep])
+    L.check(L.lib().rpg_linear_gather_ex_f32(ns, a_arr, i_arr, ld, wd, rows, _p(weight), _p(bias), _p(residual), _p(res_idx), _p(residual2),
+                                              _p(res2_idx), 0 if residual is None else residual.shape[1], _p(out), _p(out_relu), m, n_out,
+                                              int(relu), _stream()), "linear_gather_ex")
+    return (out, out_relu) if want_relu_copy else out
+
+
 def attention_rows(gtp: torch.Tensor) -> torch.Tensor:
     gtp = _req(gtp, "gtp")
     r, c3 = gtp.shape

@@ -557,6 +557,10 @@ class PoseNetX_R2(nn.Module):  # noqa: N801 - reference spelling
             ev.synchronize()
             total, bad = int(meta_h[0]), int(meta_h[1])
             if bad:
+                # every slot's encoder + kNN work is already enqueued on the side streams and reads the caller's x (e.g. a
+                # staging buffer the caller refills once this call returns OR raises): join them before leaving
+                for st_ in self._streams[:n_slots]:
+                    cur.wait_stream(st_)
                 raise ValueError("knn_graph: a graph has more than 2048 nodes (unsupported)")
             st = self._streams[slot]
             with torch.cuda.stream(st):

@@ -140,11 +140,14 @@ def _slice_in_order(local_rank: int, local_world: int, ordered: Sequence[int]) -
 
 
 def bind_rank_to_host_slice(local_rank: int, local_world: int, device_index: Optional[int] = None) -> Optional[List[int]]:
-    """Pin the calling process (and every thread it starts afterwards: staging pools inherit the mask; pinned buffers
-    allocated afterwards are first touched from these CPUs) to its share of the host: the CPUs of its GPU's NUMA node
+    """Pin the calling THREAD and every thread started afterwards (``os.sched_setaffinity(0, ...)`` binds the caller, not the
+    threads that already exist: the HIP / RCCL runtime threads and torch's intra-op pool keep their masks; staging pools created
+    afterwards inherit the new one, and pinned buffers allocated afterwards are first touched from these CPUs) to its share of the host: the CPUs of its GPU's NUMA node
     where sysfs names them -- cut among the ranks whose GPUs share that node -- else an equal contiguous slice of the
     current mask.  Returns the CPU list, or None if nothing was changed (single rank, RPG_BIND_RANKS=0, unsupported
-    platform).  Plain ``os.sched_setaffinity``: no exec, no numactl hop (safe after the GPU has been initialised)."""
+    platform).  Plain ``os.sched_setaffinity``: no exec, no numactl hop (safe after the GPU has been initialised).
+    Process-long when an entry script calls it (bench.py, tools/eval_stream.py: they know LOCAL_RANK); a LIBRARY call uses the
+    ``rank_host_slice`` context manager below, which puts the previous mask back."""
     global _BOUND
     if local_world <= 1 or os.environ.get("RPG_BIND_RANKS", "1") == "0" or not hasattr(os, "sched_setaffinity"):
         return None
@@ -177,3 +180,99 @@ def bind_rank_to_host_slice(local_rank: int, local_world: int, device_index: Opt
         return cpus
     except Exception:
         return None
+
+
+class rank_host_slice:
+    """``with rank_host_slice(local_rank, local_world, device_index):`` -- bind_rank_to_host_slice for the duration of the block
+    (a library call must not narrow its caller's CPU mask for good).  The threads started inside (the staging pool of
+    ``evaluate._InputPipeline``) keep the slice; the calling thread gets its previous mask back on exit.  A process its entry
+    script has already bound (``_BOUND`` set before the block) is left alone both ways."""
+
+    def __init__(self, local_rank: int, local_world: int, device_index: Optional[int] = None):
+        self.args = (local_rank, local_world, device_index)
+        self.prev = None
+        self.cpus = None
+
+    def __enter__(self):
+        global _BOUND
+        if _BOUND is None and hasattr(os, "sched_getaffinity"):
+            prev = os.sched_getaffinity(0)
+            self.cpus = bind_rank_to_host_slice(*self.args)
+            if self.cpus is not None:
+                self.prev = prev
+        elif _BOUND is not None:
+            self.cpus = _BOUND[1]
+        return self.cpus
+
+    def __exit__(self, *exc):
+        global _BOUND
+        if self.prev is not None:
+            try:
+                os.sched_setaffinity(0, self.prev)
+            finally:
+                _BOUND = None
+        return False
+
+
+# ---- a multi-rank record that diagnoses itself (round 6) ----------------------------------------------------------------
+# The reference is one process (testing/test.py:78-80): nothing in it says which of eight ranks was slow.  Every line a
+# multi-rank run prints (bench.py, tools/eval_stream.py) carries what RCCL itself observed -- not what the launcher configured.
+
+def gpu_identity(device) -> int:
+    """A 63-bit integer naming the physical GPU behind ``device``: PCI domain / bus / device where the runtime reports them,
+    else a hash of the UUID or of the device name + index.  Two ranks that (by a launcher mistake) drive the SAME GPU report
+    the same number."""
+    d = torch.device(device)
+    if d.type != "cuda":
+        return (os.getpid() << 8) | 0xff           # CPU stand-in (gloo tests): one "device" per process
+    p = torch.cuda.get_device_properties(d)
+    bus, devn = getattr(p, "pci_bus_id", None), getattr(p, "pci_device_id", None)
+    if bus is not None and devn is not None:
+        return (int(getattr(p, "pci_domain_id", 0)) << 16) | (int(bus) << 8) | int(devn)
+    import hashlib
+    key = str(getattr(p, "uuid", "")) or f"{p.name}#{d.index}"
+    return int.from_bytes(hashlib.sha256(key.encode()).digest()[:8], "big") >> 1
+
+
+def rank_report(device, elapsed_s: float, steps: int = 1, host_cpus: Optional[int] = None, identity: Optional[int] = None,
+                group=None) -> dict:
+    """Flat scalars describing the run AS THE COLLECTIVES SAW IT (every rank must call; every rank gets the same dict):
+
+      rccl_ranks_seen      all_reduce(SUM) of a one per rank -- the ranks that really took part in a collective
+      distinct_gpus        number of different gpu_identity() values among them (== ranks_seen unless ranks share a GPU)
+      distinct_hosts       number of different host names (hashed)
+      rank_ms_min / _max / _mean, slowest_rank, fastest_rank      per-rank ms per step from an all_gather of each rank's own clock
+      rank_ms_spread       (max - min) / min: one slow rank (a throttling GPU, a far socket) shows here, a slow collective does not
+      host_cpus_min / _max CPUs in each rank's affinity mask (bind_rank_to_host_slice), min / max over ranks
+      numa_nodes_seen      distinct NUMA nodes of the ranks' GPUs (-1 entries = unknown are counted once)
+
+    Works on any backend (the tensors live on ``device`` for nccl, on the CPU for gloo)."""
+    d = torch.device(device)
+    if not (dist.is_available() and dist.is_initialized()):
+        ms = 1e3 * elapsed_s / max(1, steps)
+        return {"rccl_ranks_seen": None, "distinct_gpus": 1, "distinct_hosts": 1, "rank_ms_min": round(ms, 3), "rank_ms_max": round(ms, 3),
+                "rank_ms_mean": round(ms, 3), "slowest_rank": 0, "fastest_rank": 0, "rank_ms_spread": 0.0,
+                "host_cpus_min": host_cpus, "host_cpus_max": host_cpus, "numa_nodes_seen": 1}
+    world = dist.get_world_size(group)
+    tdev = d if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    ones = torch.ones(1, dtype=torch.int64, device=tdev)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM, group=group)
+    import hashlib
+    import socket
+    host_hash = int.from_bytes(hashlib.sha256(socket.gethostname().encode()).digest()[:7], "big")
+    ident = gpu_identity(d) if identity is None else int(identity)
+    numa = gpu_numa_node(d.index) if d.type == "cuda" else None
+    if host_cpus is None and hasattr(os, "sched_getaffinity"):
+        host_cpus = len(os.sched_getaffinity(0))
+    mine = torch.tensor([ident, host_hash, int(round(1e6 * elapsed_s / max(1, steps))), int(host_cpus or 0), -1 if numa is None else int(numa)],
+                        dtype=torch.int64, device=tdev)
+    allr = torch.empty(world * mine.numel(), dtype=torch.int64, device=tdev)
+    dist.all_gather_into_tensor(allr, mine, group=group)
+    rows = allr.view(world, mine.numel()).cpu().tolist()
+    ms = [r[2] / 1e3 for r in rows]
+    lo, hi = min(ms), max(ms)
+    return {"rccl_ranks_seen": int(ones.item()), "distinct_gpus": len({(r[1], r[0]) for r in rows}), "distinct_hosts": len({r[1] for r in rows}),
+            "rank_ms_min": round(lo, 3), "rank_ms_max": round(hi, 3), "rank_ms_mean": round(sum(ms) / len(ms), 3),
+            "slowest_rank": ms.index(hi), "fastest_rank": ms.index(lo), "rank_ms_spread": round((hi - lo) / lo, 4) if lo > 0 else None,
+            "host_cpus_min": min(r[3] for r in rows), "host_cpus_max": max(r[3] for r in rows),
+            "numa_nodes_seen": len({r[4] for r in rows})}

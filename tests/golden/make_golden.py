@@ -314,7 +314,7 @@ def main():
     ei8 = O.fc_edge_index(8)
     y8 = S.hash_normal("g9.y", (8, 6), 0.3, 0.0, seed=9)
     os.makedirs(os.path.join(HERE, "processed"), exist_ok=True)
-    torch.save(Data(x=x4[:8].view(8, -1).clone(), edge_index=ei8, y=y8, edge_attr=y8[ei8[0]] - y8[ei8[1]]),
+    torch.save(Data(x=x4[:8].view(8, -1).clone(), edge_index=ei8, y=y8, edge_attr=y8[ei8[1]] - y8[ei8[0]]),        # y[target] - y[source], dataset_7Scenes_multi.py:425-429
                os.path.join(HERE, "processed", "data_000000.pt"))
     for n in pyg:
         sys.modules.pop(n, None)

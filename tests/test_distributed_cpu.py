@@ -164,3 +164,71 @@ def test_rank_host_slices_partition_the_cpus():
     p.join(30)
     assert got == sorted(shard._slice_in_order(1, 2, shard._core_major(before)))          # whole cores, SMT siblings together
     assert again == got and after == got and sorted(os.sched_getaffinity(0)) == before
+
+
+def _report_worker(rank, world, port, out_dir, share_gpu):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import json
+    from relpose_gnn_amd.shard import rank_report
+    # rank r "took" (10 + r) ms per step over 4 steps; rank 1 is given 3 CPUs, the others 2; with share_gpu ranks 0 and 1 claim
+    # the same device identity (a launcher that forgot LOCAL_RANK)
+    ident = 1000 + (0 if (share_gpu and rank == 1) else rank)
+    rep = rank_report("cpu", 4 * (10 + rank) * 1e-3, steps=4, host_cpus=3 if rank == 1 else 2, identity=ident)
+    with open(os.path.join(out_dir, f"rep{rank}.json"), "w") as f:
+        json.dump(rep, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,share_gpu", [(2, False), (8, False), (8, True)])
+def test_rank_report_diagnoses_a_multi_rank_run(tmp_path, world, share_gpu):
+    """Round 6: the fields a `--gpus N` line carries come from collectives, not from the launcher's
+    configuration -- ranks that took part (all_reduce of ones), distinct devices (all_gather of each rank's device identity:
+    two ranks on one GPU show as distinct_gpus < ranks), per-rank step time min / max / which rank, CPUs per rank.  Same dict
+    on every rank."""
+    import json
+    mp.spawn(_report_worker, args=(world, _free_port(), str(tmp_path), share_gpu), nprocs=world, join=True)
+    reps = [json.load(open(os.path.join(str(tmp_path), f"rep{r}.json"))) for r in range(world)]
+    assert all(r == reps[0] for r in reps[1:])
+    r = reps[0]
+    assert r["rccl_ranks_seen"] == world
+    assert r["distinct_gpus"] == (world - 1 if share_gpu else world) and r["distinct_hosts"] == 1
+    assert r["rank_ms_min"] == 10.0 and r["rank_ms_max"] == 10.0 + world - 1 and r["fastest_rank"] == 0 and r["slowest_rank"] == world - 1
+    assert abs(r["rank_ms_spread"] - (world - 1) / 10.0) < 1e-3 and abs(r["rank_ms_mean"] - (10.0 + (world - 1) / 2)) < 1e-3
+    assert r["host_cpus_min"] == 2 and r["host_cpus_max"] == 3
+
+
+def test_rank_report_without_a_process_group():
+    from relpose_gnn_amd.shard import rank_report
+    r = rank_report("cpu", 0.05, steps=5, host_cpus=7)
+    assert r["rccl_ranks_seen"] is None and r["rank_ms_max"] == 10.0 and r["distinct_gpus"] == 1 and r["host_cpus_min"] == 7
+
+
+def test_rank_host_slice_restores_the_callers_mask():
+    """a library call (evaluate_stream) must not narrow its caller's CPU mask for good -- shard.rank_host_slice binds
+    for the duration of a block and puts the previous mask back; a process its entry script bound is left alone."""
+    import multiprocessing as pmp
+    ctx = pmp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_slice_child, args=(q,))
+    p.start()
+    before, inside, after, inside2, after2 = q.get(timeout=60)
+    p.join(timeout=30)
+    if len(before) < 2:
+        pytest.skip("one CPU: nothing to narrow")
+    assert inside is not None and set(inside) < set(before) and after == before       # narrowed inside, restored after
+    assert inside2 == inside and after2 == sorted(inside)                              # bound by the "entry script": left alone both ways
+
+
+def _slice_child(q):
+    from relpose_gnn_amd import shard
+    before = sorted(os.sched_getaffinity(0))
+    with shard.rank_host_slice(0, 2) as cpus:
+        inside = sorted(os.sched_getaffinity(0))
+        assert cpus is None or sorted(cpus) == inside
+    after = sorted(os.sched_getaffinity(0))
+    shard.bind_rank_to_host_slice(0, 2)                     # process-long (what bench.py / tools/eval_stream.py do)
+    with shard.rank_host_slice(0, 2):
+        inside2 = sorted(os.sched_getaffinity(0))
+    q.put((before, inside, after, inside2, sorted(os.sched_getaffinity(0))))

@@ -211,7 +211,7 @@ def test_reference_written_checkpoint_and_sample(golden_dir):
     d = rio.load_graph(files[0])
     assert "torch_geometric" not in sys.modules
     assert torch.equal(d.x, S.synth_images(16, 32, 40, seed=3)[:8]) and torch.equal(d.edge_index, fc_edge_index(8))
-    assert d.y.shape == (8, 6) and torch.equal(d.edge_attr, d.y[d.edge_index[0]] - d.y[d.edge_index[1]])
+    assert d.y.shape == (8, 6) and torch.equal(d.edge_attr, d.y[d.edge_index[1]] - d.y[d.edge_index[0]])
     g = np.load(os.path.join(golden_dir, "g4_full_small.npz"))
     a, r, _ = O.posenet_forward(sd, d.x, d.edge_index, 32, 2)
     assert float((a - torch.from_numpy(g["abs"][:8])).abs().max()) < 1e-5 * float(np.abs(g["abs"]).max())

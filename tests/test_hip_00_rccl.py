@@ -46,6 +46,9 @@ assert gather_rows(rel, [5]) is rel                            # default: a sing
 t = torch.tensor([3.5], dtype=torch.float64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 assert float(t.item()) == 3.5
+from relpose_gnn_amd.shard import rank_report
+rep = rank_report(dev, 0.02, steps=2)                          # all_reduce of ones + all_gather of the device identities over RCCL
+assert rep["rccl_ranks_seen"] == 1 and rep["distinct_gpus"] == 1 and rep["rank_ms_max"] == 10.0 and rep["slowest_rank"] == 0, rep
 dist.barrier()
 torch.cuda.synchronize()
 dist.destroy_process_group()
@@ -69,6 +72,10 @@ def test_bench_through_its_own_launcher_world1():
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["process_group"].startswith("nccl (RCCL), world_size=1")
+    cfg = rec["config"]                                      # round 6: what the collectives observed, as flat scalars
+    assert rec["rccl_ranks_seen"] == 1 and cfg["distinct_gpus"] == 1 and cfg["slowest_rank"] == 0 and cfg["allgather_ms"] > 0
+    assert abs(cfg["rank_ms_max"] - rec["ms_per_step"]) / rec["ms_per_step"] < 0.2 and isinstance(cfg["loaded_library"], str)
+    assert all(not isinstance(v, (dict,)) for v in cfg.values())
 
 
 def test_eval_stream_tool_under_its_launcher_world1():
@@ -83,3 +90,4 @@ def test_eval_stream_tool_under_its_launcher_world1():
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["rccl_ranks_seen"] == 1 and rec["graphs"] == 24 and rec["graphs_per_s"] > 0
+    assert rec["distinct_gpus"] == 1 and rec["slowest_rank"] == 0 and rec["rank_ms_max"] > 0 and rec["staged_gb"] > 0 and rec["direct_gb"] == 0

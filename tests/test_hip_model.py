@@ -388,6 +388,11 @@ def test_eval_stream_input_pipeline_variants_agree(dev):
         # micro-batches bypass the pipeline and only the last one (graph 15 alone, host-resident: 7 x 3 x 32 x 40 floats) is staged
         want = {"resident": 0, "device_and_host": sizes[15] * 3 * 32 * 40 * 4}.get(kind, sum(sizes) * 3 * 32 * 40 * 4)
         assert st["micro_batches"] == 6 and st["h2d_bytes"] == want, (kind, st)
+        # round 6: the reference's loader delivers PINNED tensors (DataLoader(pin_memory=True), test.py:193) --
+        # those must go to the device straight from where they are, with no pageable -> pinned staging copy in between
+        per = 3 * 32 * 40 * 4
+        want_direct = {"pinned": sum(sizes) * per, "mixed": sum(n for i, n in enumerate(sizes) if i % 3 == 1) * per}.get(kind, 0)
+        assert st["direct_bytes"] == want_direct and st["staged_bytes"] == want - want_direct, (kind, st)
     # device_and_host: every micro-batch mixes graphs that live on the device with graphs in host memory (used to
     # die in torch.cat); they are collated on the device, outside the staging pipeline
     for kind in ("pinned", "mixed", "resident", "device_and_host"):
@@ -752,6 +757,45 @@ def test_reference_eval_loop_through_lookahead(dev, knn):
     assert np.allclose(ahead_p, plain_p, atol=2e-5) and np.array_equal(ahead_t, plain_t)
     res = E.evaluate_stream(m, graphs, dev, micro_batch=4, pose_m=pose_m, pose_s=pose_s)
     assert np.allclose(ahead_p, res.pred_poses, atol=5e-6)   # the same micro-batches through the same pipeline
+
+
+def test_lookahead_direct_calls_are_ordered_and_announced(dev):
+    """A call inside the wrapped loop that does not present the graph just yielded (here: data.x cloned) runs the module directly:
+    correct results, counted in ``direct_calls``, announced ONCE by a RuntimeWarning (round 6), and ordered against the batched
+    forwards in BOTH directions (with one stream both use the module's default workspaces) -- the poses of every
+    graph still equal the plain loop's."""
+    import warnings
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd.graph import Batch, Data, fc_edge_index
+    from relpose_gnn_amd.lookahead import lookahead
+    m, _ = _build(64, 32, (8, 16, 32, 64), (1, 1, 1, 1), dev)
+    m.hip_streams = 1
+    graphs = [Data(x=S.synth_images(8, 32, 40, seed=900 + i), edge_index=fc_edge_index(8), y=S.hash_normal(f"ld.y{i}", (8, 6), 0.3)) for i in range(9)]
+
+    class Loader:
+        batch_size = 1
+
+        def __len__(self):
+            return len(graphs)
+
+        def __iter__(self):
+            return (Batch.from_data_list([g]) for g in graphs)
+
+    plain = [m(Batch.from_data_list([g]).to(dev))[1].cpu() for g in graphs]
+    loader, wrapped = lookahead(Loader(), m, dev, micro_batch=2)
+    got = []
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for i, data in enumerate(loader):
+            d = data.to(dev)
+            if i % 2 == 1:
+                d.x = d.x.clone()                    # not the ticket any more: falls to a direct forward, no synchronisation here
+            got.append(wrapped(d)[1])
+    got = [g.cpu() for g in got]
+    assert wrapped.direct_calls == 4 and wrapped.forwards == 5
+    assert sum(issubclass(x.category, RuntimeWarning) and "lookahead" in str(x.message) for x in w) == 1
+    for a, b in zip(got, plain):
+        assert torch.allclose(a, b, atol=2e-5, rtol=1e-5)
 
 
 def test_foreign_torchvision_style_feature_extractor(dev):

@@ -641,7 +641,8 @@ def test_linear_exact_fit_112_row_tiles(dev, m, k, n_out, res, relu):
     """Round 5: Linears with M = 7 * 2^k rows (the GNN's edge GEMMs: 56 edges x graphs) on 112 x 64 tiles of
     v_mfma_f32_16x16x4_f32 -- no stream-K split, no fix-up launch (RPG_TUNE_LIN112 = 1, csrc/gemm_f32.hip linear112_kernel;
     reference op: nn.Linear of my_gnn_layer.py:236-239,304-311).  Against F.linear on the CPU (1e-5 like every fp32 op test)
-    and against the 32x32x2 tile engine on the same operands (= 0): K % 32 tails that are not a multiple of the fold length,
+    and against the 32x32x2 tile engine on the same operands (same bar: the two kernels sum in different orders, so they agree
+    to rounding, not bit for bit): K % 32 tails that are not a multiple of the fold length,
     K = 96 (three steps: odd step count), residual rows, ReLU, 1 / 2 / 4 tiles per CU."""
     from relpose_gnn_amd import ops
     a = _rand(m, k, seed=31)
@@ -664,3 +665,42 @@ def test_linear_exact_fit_112_row_tiles(dev, m, k, n_out, res, relu):
     for mode in (3, 1, 0):
         assert rel_err(outs[mode], ref) < TOL, (mode, rel_err(outs[mode], ref))
     assert rel_err(outs[1], outs[0]) < TOL and rel_err(outs[3], outs[0]) < TOL
+
+
+@pytest.mark.parametrize("m,nodes,k,pad_a,pad_r", [(1792, 256, 2048, 64, 0), (896, 128, 2048, 0, 64), (1792, 256, 1024, 32, 32)])
+def test_linear_exact_fit_112_epilogue_and_strided_a(dev, m, nodes, k, pad_a, pad_r):
+    """The exact-fit 112-row kernels share the tile engine's epilogue code (streamk_finish_quad) and its buffer-offset
+    arithmetic; until round 6 only the whole GNN forward exercised them there.  Through rpg_linear_gather_ex_f32:
+    a plain A operand that is a column block of a wider tensor (row pitch > K), TWO gathered residual rows per output row (the
+    node terms of the split edge Linears, my_gnn_layer.py:236-239: W_src x[src] + W_dst x[dst]) out of tensors whose pitch may exceed
+    n_out, bias, ReLU, and the max(out, 0) second output -- on the four-wave kernel, its eight-wave form and the engine."""
+    from relpose_gnn_amd import ops
+    n_out = 2048
+    a_wide = _rand(m, k + pad_a, seed=41)
+    wt = _rand(n_out, k, seed=42, scale=k ** -0.5)
+    bias = _rand(n_out, seed=43, scale=0.1)
+    r1 = _rand(nodes, n_out + pad_r, seed=44)
+    r2 = _rand(nodes, n_out + pad_r, seed=45)
+    g = torch.Generator().manual_seed(46)
+    i1 = torch.randint(0, nodes, (m,), generator=g)
+    i2 = torch.randint(0, nodes, (m,), generator=g)
+    pre = F.linear(a_wide[:, :k], wt, bias) + r1[i1, :n_out] + r2[i2, :n_out]
+    outs = {}
+    try:
+        for mode in (3, 1, 0):
+            ops.set_tuning(ops.TUNE_LIN112, mode)
+            for relu in (False, True):
+                o, o_relu = ops.linear_gather_ex([(a_wide.to(dev), None)], wt.to(dev), bias.to(dev), m, r1.to(dev), i1.to(dev), r2.to(dev),
+                                                 i2.to(dev), relu=relu, want_relu_copy=True, widths=[k])
+                outs[(mode, relu)] = (o.cpu(), o_relu.cpu())
+    finally:
+        ops.set_tuning(ops.TUNE_LIN112, 3)
+    for (mode, relu), (o, o_relu) in outs.items():
+        want = F.relu(pre) if relu else pre
+        assert rel_err(o, want) < TOL, (mode, relu, rel_err(o, want))
+        assert torch.equal(o_relu, F.relu(o)) or rel_err(o_relu, F.relu(pre)) < TOL, (mode, relu)
+    # plain (un-gathered) residual through the same entry point == rpg_linear_gather_f32
+    ops.set_tuning(ops.TUNE_LIN112, 3)
+    res = _rand(m, n_out, seed=47)
+    o = ops.linear_gather_ex([(a_wide.to(dev), None)], wt.to(dev), bias.to(dev), m, res.to(dev), relu=True, widths=[k]).cpu()
+    assert rel_err(o, F.relu(F.linear(a_wide[:, :k], wt, bias) + res)) < TOL

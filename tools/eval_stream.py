@@ -56,6 +56,11 @@ def main():
     if under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if world > 1:
+            # process-long host placement is the ENTRY SCRIPT's decision (it knows LOCAL_RANK); evaluate_stream itself only
+            # binds for the duration of a call and leaves a process bound here alone
+            from relpose_gnn_amd.shard import bind_rank_to_host_slice
+            bind_rank_to_host_slice(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), local)
     import relpose_gnn_amd.synth as S
     from relpose_gnn_amd import evaluate as E
     from relpose_gnn_amd.posenet import PoseNetX_R2
@@ -102,6 +107,8 @@ def main():
     if under_launcher:
         dist.barrier()
     dt = time.perf_counter() - t0
+    from relpose_gnn_amd.shard import rank_report
+    report = rank_report(dev, stats.get("local_seconds", dt), 1)          # collective; this rank's own clock over its block of the stream
     if under_launcher:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -113,8 +120,12 @@ def main():
                                       f"node images {args.input} ({'pinned double-buffered H2D on a copy stream' if args.input != 'resident' else 'no H2D'}"
                                       f"{', staged as bf16' if args.input != 'resident' and (bfin if bfin is not None else model.accepts_bf16_input) else ''}), "
                                       "D2H + test.py post-processing per graph included",
-                          "input": args.input, "n_gpus": world, "rccl_ranks_seen": dist.get_world_size() if under_launcher else None,
-                          "cpu_affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "graphs": args.graphs, "seconds": round(dt, 3),
+                          "input": args.input, "n_gpus": world,
+                          # what the collectives observed (shard.rank_report): ranks that took part, distinct GPUs / hosts / NUMA nodes,
+                          # each rank's own milliseconds over ITS block of the stream (rank_ms_min / _max / _mean, slowest_rank), CPUs per rank
+                          **report,
+                          "staged_gb": round(stats.get("staged_bytes", 0) / 1e9, 3), "direct_gb": round(stats.get("direct_bytes", 0) / 1e9, 3),
+                          "staging_workers": stats.get("staging_workers"), "graphs": args.graphs, "seconds": round(dt, 3),
                           "graphs_per_s": round(args.graphs / dt, 1),
                           "h2d_gb_per_s": round(stats.get("h2d_bytes", 0) / dt / 1e9, 2)}), flush=True)
     if under_launcher:
