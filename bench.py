@@ -261,7 +261,7 @@ def other_configs(model, args, dev):
         for name, dt_name, n in (("configs3_eval_stream_1gpu_host_fp32", "f32", 2000), ("configs4_eval_stream_1gpu_host_bf16", "bf16", 4000)):
             model.encoder_dtype = model.gnn_dtype = dt_name
             legs = {}
-            for leg, src, bfin in (("pinned", pinned_pool, None), ("pageable", pool, None)) + ((("pinned_f32_h2d", pinned_pool, False),) if dt_name == "bf16" else ()):
+            for leg, src, bfin in (("pinned", pinned_pool, None), ("pageable", pool, None)) + ((("pinned_host_rounded", pinned_pool, True),) if dt_name == "bf16" else ()):
                 graphs = [Data(x=src[i % len(src)][0], edge_index=ei8, y=src[i % len(src)][1]) for i in range(n)]
                 E.evaluate_stream(model, graphs[:2 * mb], dev, micro_batch=mb, bf16_input=bfin)   # warm-up: packing, workspaces, staging buffers
                 torch.cuda.synchronize()
@@ -277,14 +277,15 @@ def other_configs(model, args, dev):
                 del graphs
             prim = legs["pinned"]
             out[name] = {"value": prim["value"], "unit": "graphs/s", "seconds": prim["seconds"], "graphs": n, "input": "pinned",
-                         "dtype": "f32" if dt_name == "f32" else "bf16 encoder + bf16 GNN Linears (f32 accumulate), images staged as bf16",
+                         "dtype": "f32" if dt_name == "f32" else "bf16 encoder + bf16 GNN Linears (f32 accumulate)",
                          "h2d_gb_per_s": prim["h2d_gb_per_s"], "legs": legs,
                          "workload": f"BASELINE.json configs[{3 if dt_name == 'f32' else 4}] shape on ONE GPU: {n} 8-node FC graphs of {h}x{w} synthetic "
                                      f"images in PINNED host memory (the reference's DataLoader(pin_memory=True), test.py:193) -> evaluate_stream "
                                      f"(micro-batch {mb}, H2D on a copy stream"
                                      + (": fp32 sources go straight from the loader's pinned tensors, no staging copy" if dt_name == "f32" else
-                                        ": the fp32 sources are rounded to bf16 by the staging threads on the way, half the H2D bytes; leg "
-                                        "pinned_f32_h2d sends them as they are")
+                                        ": pinned fp32 sources go straight from the loader's tensors as they are -- no rounding pass, no staging "
+                                        "copy; leg pinned_host_rounded forces the staging threads' bf16 rounding (half the H2D bytes), which is what "
+                                        "pageable sources get")
                                      + ", D2H + test.py:213-251 post-processing per graph included); legs.pageable = the same stream out of "
                                      "pageable memory; the 4- / 8-GPU sharding is tools/eval_stream.py under torch.distributed.run"}
         del pinned_pool

@@ -123,9 +123,13 @@ int rpg_resnet_forward_f32(const float* const* tensors, int n_tensors, const int
  *                                posenet.py:1037): x_nchw fp32 [n][3][h][w] -> y bf16 [n][hp][wp][64]; inputs and weights
  *                                rounded to bf16, fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 scale / shift / ReLU /
  *                                max, one bf16 rounding at the store.
- *                                wpack_bf16 [11][2][64][8] bf16: element [s][nf][l][j] = W[ch = 32 nf + (l & 31)][c][kh][kw = j]
- *                                with (c, kh) = divmod(2 s + (l >> 5), 7); zero for j == 7 and for the 22nd (c, kh) row
- *                                (relpose-gnn_amd/params.py pack_stem_bf16 builds it).                                   */
+ *                                wpack_bf16: two operand images back to back (23,552 bf16).  [11][2][64][8]: element
+ *                                [s][nf][l][j] = W[ch = 32 nf + (l & 31)][c][kh][kw = j] with (c, kh) = divmod(2 s + (l >> 5), 7);
+ *                                zero for j == 7 and for the 22nd (c, kh) row (the tile kernel of rounds 3-5,
+ *                                RPG_TUNE_FUSED_STEM = 3).  Then [2][3][4][64][8]: element [nf][c][j][l][t] =
+ *                                W[ch = 32 nf + (l & 31)][c][kh = 2 j + (l >> 5)][kw = t - 1]; zero for t == 0 and kh == 7 (the
+ *                                strip-march kernel of round 6, the default).  relpose-gnn_amd/params.py pack_stem_bf16
+ *                                builds both.                                                                             */
 int rpg_stem_conv7x7s2_bn_relu_maxpool_bf16(const float* x_nchw, const void* wpack_bf16, const float* scale, const float* shift,
                                             void* y_nhwc_bf16, int n, int h, int w, void* stream);
 /* ... and on node images that are ALREADY bf16 [n][3][h][w] (the reference's fp32 `data.x`, posenet.py:1034-1035, rounded to bf16
@@ -321,7 +325,10 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
                                      attention rows, att.W on edge rows, separate scatter-mean (the reference's order) */
 #define RPG_TUNE_WAVES8 11        /* 1: 8-wave workgroups (two waves per SIMD) for the 128x128 / 128x64 tiles of the f32 tile engine where
                                      the buffer-load path applies (default) | 0: always 4-wave workgroups */
-#define RPG_TUNE_FUSED_STEM 10    /* 1: one-kernel stem (conv7x7 + BN + ReLU + max-pool) where its operands are given (default) | 0: three kernels */
+#define RPG_TUNE_FUSED_STEM 10    /* bit 0: one-kernel stem (conv7x7 + BN + ReLU + max-pool) where its operands are given (default 1) | 0: three kernels.
+                                     bf16 stem only: bit 1 = the tile kernel of rounds 3-5 instead of the strip-march kernel of round 6; bit 2 = the
+                                     strip-march kernel keeps its weights in registers (two waves per SIMD) instead of LDS (three); value >> 4 =
+                                     pooled rows per band of the strip-march kernel (0, the default: by the launch's size) */
 #define RPG_TUNE_WINO_SPLIT 8     /* 1: split-K tail + fix-up for the 8-wave Winograd kernel (default) | 0: whole tiles only | n >= 2: as 1, and a part of a
                                      tile gets at least n K steps in the one-workgroup-per-tile form (default 3: one 8-node graph 1.50 ms per forward, 1.63 with 4) */
 #define RPG_TUNE_FAST_LOADER 7    /* 1: buffer-load loaders + interleaved main loop where eligible (default) | 0: general loaders */

@@ -95,6 +95,7 @@ void bf16_set_tile(int t);
 void bf16_set_dma(int v);
 void bf16_set_patch(int v);
 void bf16_set_fused_stem(int on);
+void bf16_set_stem_strip(int on, int band_rows);   // stem_bf16.hip: strip-march kernel (round 6) | tile kernel (rounds 3-5)
 void bf16_set_chunk(int images, int min_mb);
 void bf16_set_lean_epi(int on);
 void bf16_set_persist(int v);

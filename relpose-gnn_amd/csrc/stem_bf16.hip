@@ -232,6 +232,265 @@ __global__ __launch_bounds__(SB_NT) __attribute__((amdgpu_waves_per_eu(3, 3))) v
     }
 }
 
+
+// ================================================================================================================================
+// Round 6: the same stem as STRIPS MARCHING DOWN THE IMAGE -- no input patch in LDS, no convolution tile in LDS, no barrier.
+//
+// Why: the tile kernel above spends a wave's life in serial phases (stage the patch -> barrier -> 2-3 fragments of 22 MFMAs +
+// BN / rounding / LDS stores -> barrier -> pooling pass -> barrier): 21 k cycles per tile of which 1.6 k are MFMAs, and only
+// three resident workgroups per CU hide it (r3-r5: five versions, every one bound by that chain, MFMA-busy 0.24).  Here a WAVE
+// owns 32 convolution columns x 32 output channels of one band of an image and walks down the convolution rows:
+//   * K is ordered (channel, kernel-row PAIR j, | 8 input columns): 3 x 4 MFMAs per convolution row (kernel row 7 and input
+//     column -1 of the window carry zero weights: K = 192 issued for 147 taps).  The pixel operand of (c, j) for convolution row
+//     oy is the input rows 2 oy - 3 + 2 j (+ 1 in lanes 32-63), columns 2 ox - 4 .. 2 ox + 3 -- which is exactly the operand of
+//     (c, j + 1) of row oy - 1: the 12 operands live in REGISTERS and rotate; a convolution row loads ONE new row pair per
+//     channel (3 operands instead of 11), straight from global memory into the lanes that need it (raw buffer loads, 8 consecutive
+//     columns per lane; neighbouring lanes overlap and are served by the vector L1), one row ahead of its use;
+//   * the weights are the MFMA's A operand and stay in registers (12 x 4 VGPRs per 32 channels): accumulators come out
+//     pixel-major, BatchNorm in fp32, rounded to bf16, and the 3 x 3 / 2 max-pool happens IN REGISTERS: vertically a running
+//     maximum over the rows of a pooled row (v_pk_max_i16 on the bf16 bits against a maximum that starts at +0: that is the ReLU,
+//     and bf16 rounding is monotone, so the bits equal round(max)); horizontally the lanes are ordered even columns | odd columns,
+//     so the three columns of a pooled cell are this lane, its right neighbour (DPP row_shl:1) and lane ^ 16 (ds_swizzle);
+//   * edges: image columns outside [0, W) are masked to zero after the conversion in the first / last strip only (lane-constant
+//     masks), rows outside [0, H) in a wave-uniform slow path; convolution columns outside [0, Wc) are clamped duplicates of a
+//     column of the same pooling window (a duplicate does not change a maximum).
+// Work item = (image, band of BH pooled rows, strip of <= 15 pooled columns, 32-channel half); four items per workgroup, no LDS
+// beyond the BatchNorm table.
+// ================================================================================================================================
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two floats -> one register of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32 (element-wise casts compile to two
+// conversions and a v_perm)
+__device__ __forceinline__ unsigned pk2_bf16(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+constexpr int SS_NT = 256;
+constexpr int SS_TP = 15;                  // pooled columns per strip: 2 * 15 + 1 = 31 of the 32 convolution columns
+struct StemSArgs {
+    const void* x;
+    const uint4* wpack;    // [2 nf][3 c][4 j][64 lanes] x 8 bf16 (params.pack_stem_bf16, second part)
+    const float* scale;
+    const float* shift;
+    __bf16* out;
+    int N, H, W, Hc, Wc, Hp, Wp;
+    int TP, tiles_x, BH, bands;
+    unsigned items;        // N * bands * tiles_x * 2
+};
+
+// WLDS: the weights live in LDS (24 KB per workgroup, one ds_read_b128 per MFMA) and the kernel fits three waves per SIMD;
+// !WLDS: in registers (48 VGPRs), two waves per SIMD.
+template <typename TIn, bool WLDS>
+__global__ __launch_bounds__(SS_NT) __attribute__((amdgpu_waves_per_eu(WLDS ? 3 : 2, WLDS ? 3 : 2))) void stem_strip_bf16_kernel(StemSArgs a) {
+    constexpr int ESZ = (int)sizeof(TIn);
+    constexpr int NLD = ESZ == 4 ? 2 : 1;                 // 16-byte loads per 8-column window
+    constexpr unsigned SENT = 0x80000000u;
+    __shared__ __attribute__((aligned(16))) float aff[128];
+    const int tid = threadIdx.x, lane = tid & 63, l = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ uint4 wl[WLDS ? 2 * 12 * 64 : 1];
+    if (tid < 128) aff[tid] = tid < 64 ? a.scale[tid] : a.shift[tid - 64];
+    if constexpr (WLDS) {
+#pragma unroll
+        for (int i = 0; i < 2 * 12 * 64 / SS_NT; ++i) wl[tid + i * SS_NT] = a.wpack[tid + i * SS_NT];
+    }
+    __syncthreads();
+    // workgroups b and b + 8 sit on the same XCD: give them neighbouring items (the strips of one band share their input rows)
+    const unsigned b = blockIdx.x, nb = gridDim.x;
+    unsigned wg = b;
+    if ((nb & 15u) == 0) { const unsigned xcd = b & 7u, k = b >> 3; wg = ((k >> 1) * 8u + xcd) * 2u + (k & 1u); }
+    const unsigned item = wg * 4u + (unsigned)wave;
+    if (item >= a.items) return;
+    const int nf = (int)(item & 1u);
+    unsigned rest = item >> 1;
+    const int strip = (int)(rest % (unsigned)a.tiles_x); rest /= (unsigned)a.tiles_x;
+    const int band = (int)(rest % (unsigned)a.bands);
+    const int n = (int)(rest / (unsigned)a.bands);
+    const int Q0 = strip * a.TP, P0 = band * a.BH;
+    const int nq = a.TP < a.Wp - Q0 ? a.TP : a.Wp - Q0, np = a.BH < a.Hp - P0 ? a.BH : a.Hp - P0;
+    const int H = a.H, W = a.W;
+
+    // ---- lane geometry: lanes 0-15 even convolution columns of the strip, 16-31 odd ones (same in both half-waves)
+    const int u = l < 16 ? 2 * l : 2 * (l - 16) + 1;
+    int cx = 2 * Q0 - 1 + u;
+    cx = cx < 0 ? 0 : (cx >= a.Wc ? a.Wc - 1 : cx);
+    const int col0 = 2 * cx - 4;                          // first input column of the lane's 8-column window (zero-weight tap)
+    // byte offset of the window inside an input row; lanes 32-63 read the NEXT row.  The row's own offset is added per load (in the
+    // vector offset: the descriptor's range check covers vector offset only, and the records end with the image)
+    const size_t img_elems = (size_t)3 * H * W;
+    // bf16 images of odd size start at a 2-byte boundary for odd n: the descriptor starts at the dword below (`mis` elements early)
+    const int mis = ESZ == 2 ? (int)(((size_t)n * img_elems) & 1) : 0;
+    const unsigned vbase = (unsigned)((col0 + h * W + mis) * ESZ);
+    // The one place where such a window starts in front of the descriptor's base is row 0 of plane 0 (columns -4 .. -1 of the first
+    // strip; with images narrower than 4 pixels the first rows of the other planes too): a negative vector offset is out of range as
+    // a whole, also for the part of a 16-byte load that lies inside the row (offset + instruction offset is not evaluated modulo
+    // 2^32).  Loads of a row pair that starts less than 4 elements into the image begin at column 0 instead and the registers are
+    // moved `lsh` bf16 pairs up afterwards -- exact for any row (wave-uniform slow path, once per image).
+    const int lsh = col0 < 0 ? (-col0) >> 1 : 0;          // 0, 1 or 2 pairs
+    unsigned cmask[4];                                    // column validity of the four bf16 pairs of the window
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c0 = col0 + 2 * i;
+        cmask[i] = ((unsigned)c0 < (unsigned)W ? 0x0000ffffu : 0u) | ((unsigned)(c0 + 1) < (unsigned)W ? 0xffff0000u : 0u);
+    }
+    const int cfirst = 2 * (2 * Q0 - 1) - 4, clast = 2 * (2 * Q0 - 1 + 31) + 3;
+    const bool edge_cols = cfirst < 0 || clast >= W;      // wave-uniform: only the first / last strip mask
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<TIn*>(reinterpret_cast<const TIn*>(a.x) + (size_t)n * img_elems - mis), 0, (unsigned)(((img_elems + mis) * ESZ + 3) & ~(size_t)3), 0x00020000);       // (whole dwords: the last bf16 of an odd-sized image shares its dword with 2 bytes
+                                                                                     //  of the next image / of the allocation's padding)
+
+    // ---- weights: A operands, resident
+    bf16x8 wreg[WLDS ? 1 : 3][WLDS ? 1 : 4];
+    if constexpr (!WLDS) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wreg[c][j] = __builtin_bit_cast(bf16x8, a.wpack[((nf * 3 + c) * 4 + j) * 64 + lane]);
+    }
+    const uint4* const wl_lane = wl + (WLDS ? nf * 12 * 64 + lane : 0);
+    auto weight = [&](int c, int j) -> bf16x8 {
+        if constexpr (WLDS) return __builtin_bit_cast(bf16x8, wl_lane[(c * 4 + j) * 64]);
+        else return wreg[c][j];
+    };
+
+    bf16x8 op[3][4];                                      // pixel operands; logical pair j of row oy lives in slot (j + oy) & 3
+    uint4 raw[3][NLD];                                    // the row pair in flight
+    // bf16 input of ODD width: every other row starts at a 2-byte boundary, and dword loads need 4: such launches load 5 dwords
+    // from the aligned address below and funnel-shift them by 16 bits in the lanes whose row is the misaligned one
+    unsigned raw5[3];
+    const bool odd_w = ESZ == 2 && (W & 1);
+    auto issue = [&](int oy) {                            // the new pair of convolution row oy: input rows 2 oy + 3 | 2 oy + 4
+        const int ra = 2 * oy + 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            unsigned voff = vbase + (unsigned)(((c * H + ra) * W) * ESZ);
+            if ((c * H + ra) * W < 4) voff += (unsigned)(lsh * 2 * ESZ);
+            if (odd_w) {
+                voff &= ~3u;
+                raw5[c] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 16u, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) raw[c][q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16u * q, 0, 0));
+        }
+    };
+    auto pack_pair = [&](int c, int oy) -> bf16x8 {       // raw -> the MFMA operand (bf16 x 8), edges zeroed
+        uint4 p;
+        if constexpr (ESZ == 4) {
+            const float4 f0 = __builtin_bit_cast(float4, raw[c][0]), f1 = __builtin_bit_cast(float4, raw[c][NLD - 1]);
+            p.x = pk2_bf16(f0.x, f0.y); p.y = pk2_bf16(f0.z, f0.w);
+            p.z = pk2_bf16(f1.x, f1.y); p.w = pk2_bf16(f1.z, f1.w);
+        } else {
+            p = raw[c][0];
+            if (odd_w) {                                  // element offset of the row odd <=> it starts 2 bytes past a dword
+                const unsigned sh = (unsigned)(((mis + (c * H + 2 * oy + 3 + h) * W) & 1) << 4);
+                p.x = __builtin_amdgcn_alignbit(p.y, p.x, sh);
+                p.y = __builtin_amdgcn_alignbit(p.z, p.y, sh);
+                p.z = __builtin_amdgcn_alignbit(p.w, p.z, sh);
+                p.w = __builtin_amdgcn_alignbit(raw5[c], p.w, sh);
+            }
+        }
+        const int ra = 2 * oy + 3;
+        if ((c * H + ra) * W < 4) {                        // the shifted loads of the image's first row(s): pairs back to their places
+            uint4 q;
+            q.x = lsh == 0 ? p.x : 0u;
+            q.y = lsh == 0 ? p.y : (lsh == 1 ? p.x : 0u);
+            q.z = lsh == 0 ? p.z : (lsh == 1 ? p.y : p.x);
+            q.w = lsh == 0 ? p.w : (lsh == 1 ? p.z : p.y);
+            p = q;
+        }
+        if (edge_cols) { p.x &= cmask[0]; p.y &= cmask[1]; p.z &= cmask[2]; p.w &= cmask[3]; }
+        if (ra < 0 || ra + 1 >= H) {                      // a row of the pair lies outside the image (first / last rows only)
+            const bool keep = (unsigned)(ra + h) < (unsigned)H;
+            p.x = keep ? p.x : 0u; p.y = keep ? p.y : 0u; p.z = keep ? p.z : 0u; p.w = keep ? p.w : 0u;
+        }
+        return __builtin_bit_cast(bf16x8, p);
+    };
+
+    typedef unsigned u32;
+    u32 mx[8];                                            // running maximum of the pooled row in progress: bf16 pairs, >= +0
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mx[i] = 0u;
+    auto pk_max = [](u32 x, u32 y) -> u32 {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2, x), __builtin_bit_cast(s16x2, y)));
+    };
+    __bf16* const out_n = a.out + (size_t)n * a.Hp * a.Wp * 64 + 32 * nf + 4 * h;
+    auto emit = [&](int py) {                             // horizontal 3-maximum + store of pooled row py (lanes l < nq hold column Q0 + l)
+        if (py < P0 || py >= P0 + np) return;
+        u32 r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const u32 right = (u32)__builtin_amdgcn_update_dpp(0, (int)mx[i], 0x101, 0xf, 0xf, true);       // row_shl:1: lane i <- lane i + 1
+            const u32 odd = (u32)__builtin_amdgcn_ds_swizzle((int)mx[i], 0x401f);                            // lane i <- lane i ^ 16
+            r[i] = pk_max(pk_max(mx[i], right), odd);
+        }
+        if (l < nq) {
+            __bf16* o = out_n + ((size_t)py * a.Wp + Q0 + l) * 64;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 v; v.x = r[2 * g]; v.y = r[2 * g + 1];
+                *reinterpret_cast<uint2*>(o + 8 * g) = v;
+            }
+        }
+    };
+
+    const int oy_first = P0 > 0 ? 2 * P0 - 1 : 0;
+    int oy_last = 2 * (P0 + np) - 1;
+    oy_last = oy_last < a.Hc ? oy_last : a.Hc - 1;
+    // One convolution row, rotation phase R = oy & 3 (static register names: the loop below is unrolled four rows deep and starts
+    // at a multiple of four).  Rows before oy_first only bring the first row's pairs j = 0..2 into their slots.
+    // MFMA k = 4 c + j; the weight fragment of MFMA k + 2 is read behind MFMA k (three fragment registers in rotation).
+#define RPG_SS_MFMA(K, R)                                                                                                      \
+    do {                                                                                                                       \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WLDS ? wf[(K) % 3] : wreg[WLDS ? 0 : (K) / 4][WLDS ? 0 : (K) % 4],       \
+                                                      op[(K) / 4][(((K) % 4) + (R)) & 3], acc, 0, 0, 0);                       \
+        if (WLDS && (K) + 2 < 12) wf[((K) + 2) % 3] = weight(((K) + 2) / 4, ((K) + 2) % 4);                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+    } while (0)
+#define RPG_SS_ROW(R)                                                                                                          \
+    do {                                                                                                                       \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c) op[c][(3 + (R)) & 3] = pack_pair(c, oy);                                 \
+        issue(oy + 1);         /* (past the last row too: range-checked, never used) */                                        \
+        if (oy >= oy_first) {                                                                                                  \
+            f32x16 acc;                                                                                                        \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[e] = 0.f;                                                       \
+            bf16x8 wf[3];                                                                                                      \
+            if (WLDS) { wf[0] = weight(0, 0); wf[1] = weight(0, 1); }                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                                 \
+            RPG_SS_MFMA(0, R); RPG_SS_MFMA(1, R); RPG_SS_MFMA(2, R); RPG_SS_MFMA(3, R);                                        \
+            RPG_SS_MFMA(4, R); RPG_SS_MFMA(5, R); RPG_SS_MFMA(6, R); RPG_SS_MFMA(7, R);                                        \
+            RPG_SS_MFMA(8, R); RPG_SS_MFMA(9, R); RPG_SS_MFMA(10, R); RPG_SS_MFMA(11, R);                                      \
+            u32 pv[8];                                                                                                         \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                    \
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(aff + 32 * nf + 8 * g + 4 * h);                               \
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(aff + 64 + 32 * nf + 8 * g + 4 * h);                          \
+                pv[2 * g] = pk2_bf16(fmaf(acc[4 * g + 0], sc[0], sh[0]), fmaf(acc[4 * g + 1], sc[1], sh[1]));                  \
+                pv[2 * g + 1] = pk2_bf16(fmaf(acc[4 * g + 2], sc[2], sh[2]), fmaf(acc[4 * g + 3], sc[3], sh[3]));              \
+            }                                                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) mx[i] = pk_max(mx[i], pv[i]);                                        \
+            if ((R) & 1) {                                                                                                     \
+                emit((oy - 1) >> 1);                                                                                           \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) mx[i] = pk_max(pv[i], 0u);                                       \
+            }                                                                                                                  \
+        }                                                                                                                      \
+        ++oy;                                                                                                                  \
+    } while (0)
+
+    int oy = (oy_first - 3) & ~3;                         // a multiple of four at or below the first warm-up row (two's complement)
+    issue(oy);
+    while (oy <= oy_last) {
+        RPG_SS_ROW(0);
+        if (oy > oy_last) break;
+        RPG_SS_ROW(1);
+        if (oy > oy_last) break;
+        RPG_SS_ROW(2);
+        if (oy > oy_last) break;
+        RPG_SS_ROW(3);
+    }
+#undef RPG_SS_ROW
+#undef RPG_SS_MFMA
+    if (!(oy_last & 1)) emit(oy_last >> 1);               // odd Hc: the last pooled row ends on an even convolution row
+}
+
 }  // namespace
 
 namespace rpg {
@@ -258,6 +517,36 @@ static bool stem_pool_bf16_geometry(int n, int h, int w, StemBArgs& a, int& grid
     return (long)((long)n / a.nxcd + 1 + grid) * a.tiles_y * a.tiles_x * a.tiles_y * a.tiles_x < (1L << 32);
 }
 
+int g_stem_strip = 1;          // 0: the tile kernel (rounds 3-5) | 1: the strip-march kernel of round 6, weights in LDS | 5: weights in registers
+int g_stem_strip_bh = 0;       // pooled rows per band (RPG_TUNE_FUSED_STEM value >> 4, experiments); 0 = by the launch's size
+void bf16_set_stem_strip(int mode, int bh) { g_stem_strip = mode; g_stem_strip_bh = bh > 0 ? bh : 0; }
+
+static bool stem_strip_geometry(int n, int h, int w, int esz, StemSArgs& a, int& grid) {
+    if (n <= 0 || h <= 0 || w <= 0) return false;
+    a.N = n; a.H = h; a.W = w;
+    a.Hc = (h + 6 - 7) / 2 + 1; a.Wc = (w + 6 - 7) / 2 + 1;
+    a.Hp = (a.Hc + 2 - 3) / 2 + 1; a.Wp = (a.Wc + 2 - 3) / 2 + 1;
+    a.tiles_x = (a.Wp + SS_TP - 1) / SS_TP;
+    a.TP = (a.Wp + a.tiles_x - 1) / a.tiles_x;
+    if (g_stem_strip_bh > 0) {
+        a.BH = g_stem_strip_bh < a.Hp ? g_stem_strip_bh : a.Hp;
+    } else {
+        // long bands amortise a band's extra convolution row and its three warm-up row loads (512 images: 259 us with 2 bands of 28
+        // pooled rows, 270 with 4 of 14, 283 with 8 of 7), short ones fill the chip when there are few images: the fewest bands that
+        // still give two rounds of workgroups (768 resident: 256 CUs x 3), never shorter than 7 pooled rows
+        int bands = 1;
+        while ((long)n * bands * a.tiles_x * 2 / 4 < 2 * 3L * num_cus() && (a.Hp + 2 * bands - 1) / (2 * bands) >= 7) bands *= 2;
+        a.BH = (a.Hp + bands - 1) / bands;
+    }
+    a.bands = (a.Hp + a.BH - 1) / a.BH;
+    const long items = (long)n * a.bands * a.tiles_x * 2;
+    // 32-bit byte offsets inside an image (incl. the rows read past its ends), 32-bit item index
+    if ((long)3 * h * w * esz + (long)16 * w * esz >= (1L << 31) || items + 64 >= (1L << 32)) return false;
+    a.items = (unsigned)items;
+    grid = (int)((items + 3) / 4);
+    return true;
+}
+
 bool stem_pool_bf16_supported(int n, int h, int w, int cout) {
     StemBArgs a{};
     int grid = 0;
@@ -269,6 +558,27 @@ int launch_stem_pool_bf16(const void* x_nchw, int x_is_bf16, const void* wpack, 
                           int n, int h, int w, hipStream_t s) {
     if (!x_nchw || !wpack || !scale || !shift || !out || n <= 0 || h <= 0 || w <= 0 || !aligned16(out) || !aligned16(wpack))
         return RPG_ERR_BAD_ARG;
+    if (g_stem_strip) {
+        StemSArgs sa{};
+        int sgrid = 0;
+        if (stem_strip_geometry(n, h, w, x_is_bf16 ? 2 : 4, sa, sgrid)) {
+            sa.x = x_nchw; sa.scale = scale; sa.shift = shift; sa.out = reinterpret_cast<__bf16*>(out);
+            sa.wpack = reinterpret_cast<const uint4*>(wpack) + KS * NF * 64;       // second part of params.pack_stem_bf16
+            const int slot = timing_begin(RPG_TIMER_CONV, s);
+            if (g_stem_strip & 4) {
+                if (x_is_bf16) hipLaunchKernelGGL((stem_strip_bf16_kernel<__bf16, false>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+                else hipLaunchKernelGGL((stem_strip_bf16_kernel<float, false>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+            } else {
+                if (x_is_bf16) hipLaunchKernelGGL((stem_strip_bf16_kernel<__bf16, true>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+                else hipLaunchKernelGGL((stem_strip_bf16_kernel<float, true>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+            }
+            // executed: per item 2 np + 1 convolution rows x 12 MFMAs of 32 x 32 x 16
+            timing_end(slot, 2.0 * (double)n * sa.Hc * sa.Wc * 64.0 * 147.0, s,
+                       (double)sa.items * (2.0 * sa.Hp / sa.bands + 1.0) * 12.0 * 32768.0);
+            RPG_CHECK_LAUNCH("stem_conv_bn_relu_maxpool_bf16 (strips)");
+            return RPG_OK;
+        }
+    }
     StemBArgs a{};
     int grid = 0;
     if (!stem_pool_bf16_geometry(n, h, w, a, grid)) return RPG_ERR_BAD_ARG;

@@ -217,13 +217,30 @@ class _MicroBatchRunner:
     and the model on the GPU), run ONE forward over it and start the asynchronous copy of the poses (and of a model-built
     edge list) into pinned host memory.  ``launch`` returns without waiting; ``item.ev`` marks the poses' arrival."""
 
-    def __init__(self, model, device, micro_batch: int, h2d_dtype=torch.float32, local_world: int = 1, want_abs: bool = False):
+    def __init__(self, model, device, micro_batch: int, h2d_dtype=torch.float32, local_world: int = 1, want_abs: bool = False,
+                 pinned_direct: bool = True):
         self.model, self.device, self.micro_batch = model, device, int(micro_batch)
         self.h2d_dtype, self.local_world, self.want_abs = h2d_dtype, local_world, want_abs
+        # pinned_direct (the default when the caller did not force a staging dtype): a micro-batch whose fp32 images ALL sit in
+        # pinned host memory -- what the reference's DataLoader(pin_memory=True) delivers, testing/test.py:193 -- goes to the
+        # device as it is, straight from the loader's tensors, even where the model would take host-rounded bf16: the rounding
+        # pass is the only per-byte host work of the stream (16 staging threads per rank, a budget the ranks of a host share),
+        # and a Gen5 x16 link moves the fp32 images faster than those threads round them (measured round 6, one GPU: 6.0 k
+        # graphs/s against 5.5 k; at 8 ranks the staging threads' 200 GB/s aggregate ceiling no longer applies)
+        self.pinned_direct = bool(pinned_direct)
         self.on_gpu = torch.device(device).type == "cuda"
-        self.pipe: Optional[_InputPipeline] = None
+        self.pipes = {}                    # staging dtype -> _InputPipeline (at most two: the configured dtype, fp32 for pinned sources)
         self.n_batches = 0
         self.h2d_bytes = 0
+
+    @property
+    def pipe(self) -> Optional[_InputPipeline]:
+        return self.pipes.get(self.h2d_dtype) or next(iter(self.pipes.values()), None)
+
+    def pipe_stats(self) -> dict:
+        ps = list(self.pipes.values())
+        return {"staged_bytes": sum(p.staged_bytes for p in ps), "direct_bytes": sum(p.direct_bytes for p in ps),
+                "staging_workers": max((p.workers for p in ps), default=0)}
 
     def launch(self, chunk: Sequence[Data]):
         """-> (chunk, host_rel, host_ei | None, ev | None, host_abs | None, x_dev): x_dev = the chunk's node images as the
@@ -234,15 +251,19 @@ class _MicroBatchRunner:
         staged = self.on_gpu and not any(g.x.is_cuda for g in chunk)
         if staged:
             rows, width = sum(g.x.shape[0] for g in chunk), int(chunk[0].x.shape[1])
-            if self.pipe is None or not self.pipe.fits(rows, width, self.h2d_dtype):
-                if self.pipe is not None:
+            dtype = self.h2d_dtype
+            if self.pinned_direct and dtype != torch.float32 and all(g.x.dtype == torch.float32 and g.x.is_pinned() for g in chunk):
+                dtype = torch.float32                               # the loader's own pinned fp32 tensors: no rounding pass, no staging copy
+            pipe = self.pipes.get(dtype)
+            if pipe is None or not pipe.fits(rows, width, dtype):
+                if pipe is not None:
                     torch.cuda.synchronize(device)                  # a larger buffer pair replaces one that is in flight
                 cap = max(rows, max(g.x.shape[0] for g in chunk) * self.micro_batch)
-                self.pipe = _InputPipeline(torch.device(device), cap, width, self.h2d_dtype, self.local_world)
-            x_dev = self.pipe.stage(k, chunk)
+                pipe = self.pipes[dtype] = _InputPipeline(torch.device(device), cap, width, dtype, self.local_world)
+            x_dev = pipe.stage(k, chunk)
             self.h2d_bytes += x_dev.numel() * x_dev.element_size()
             batch = _collate_on_device(chunk, x_dev, device)
-            self.pipe.acquire(k)
+            pipe.acquire(k)
         else:
             if self.on_gpu and not all(g.x.is_cuda for g in chunk):
                 # a chunk that mixes device- and host-resident graphs: the host ones go over one by one, the
@@ -252,7 +273,7 @@ class _MicroBatchRunner:
                 batch = Batch.from_data_list(chunk).to(device, non_blocking=True)
         ab, rel, edge_index = model(batch)
         if staged:
-            self.pipe.release(k)
+            pipe.release(k)
         # a model-built edge list (kNN graph: the reference's default --knn 4, test.py:308, posenet.py:1047-1048) comes
         # back instead of the stored one: it travels to the host with the poses and is cut per graph by the consumer
         model_built = edge_index is not batch.edge_index
@@ -298,7 +319,10 @@ def evaluate_stream(model, graphs: Sequence[Data], device, micro_batch: int = 64
     ``stats`` (optional dict) receives ``h2d_bytes`` (bytes sent through the input pipeline), ``staged_bytes`` (of those: copied pageable -> pinned
     by the staging threads), ``direct_bytes`` (sent straight out of the caller's pinned tensors), ``staging_workers``, ``micro_batches`` and
     ``local_seconds`` (this rank's block, before the all-gather).  ``bf16_input`` (default: whatever the model
-    accepts, i.e. True for the bf16 encoder with its fused stem): host-resident images are rounded to bf16 while they are staged."""
+    accepts, i.e. True for the bf16 encoder with its fused stem): host-resident images are rounded to bf16 while they are staged --
+    except, by default, micro-batches whose fp32 images all sit in PINNED memory (the reference's loader, test.py:193): those are sent
+    as they are, with no host pass at all (``bf16_input=True`` forces the rounding pass for them too).  Same poses either way:
+    the bf16 encoder rounds fp32 input first thing."""
     from .shard import rank_host_slice
     if world > 1 and torch.device(device).type == "cuda":
         import os
@@ -320,7 +344,7 @@ def _evaluate_stream(model, graphs, device, micro_batch, pose_m, pose_s, ref_nod
     targs: List[np.ndarray] = []
     # the bf16 encoder takes its node images in bf16 (rounded while they are staged: half the H2D bytes, identical results)
     h2d_dtype = torch.bfloat16 if (bf16_input if bf16_input is not None else getattr(model, "accepts_bf16_input", False)) else torch.float32
-    runner = _MicroBatchRunner(model, device, micro_batch, h2d_dtype, local_world)
+    runner = _MicroBatchRunner(model, device, micro_batch, h2d_dtype, local_world, pinned_direct=bf16_input is None)
 
     def launch(b0):
         return runner.launch([graphs[i] for i in range(b0, min(hi, b0 + micro_batch))])
@@ -366,11 +390,8 @@ def _evaluate_stream(model, graphs, device, micro_batch, pose_m, pose_s, ref_nod
         stats["local_seconds"] = time.perf_counter() - t_local      # this rank's own block, before the all-gather
         stats["h2d_bytes"] = runner.h2d_bytes
         stats["micro_batches"] = runner.n_batches
-        pipe = runner.pipe
         # bytes that went pageable -> pinned through the staging threads / straight out of the caller's own pinned tensors
-        stats["staged_bytes"] = pipe.staged_bytes if pipe is not None else 0
-        stats["direct_bytes"] = pipe.direct_bytes if pipe is not None else 0
-        stats["staging_workers"] = pipe.workers if pipe is not None else 0
+        stats.update(runner.pipe_stats())
     pred = np.stack(preds) if preds else np.zeros((0, 7))
     targ = np.stack(targs) if targs else np.zeros((0, 7))
     import torch.distributed as dist

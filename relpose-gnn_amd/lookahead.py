@@ -62,7 +62,7 @@ class Lookahead:
             raise ValueError("micro_batch must be >= 1")
         h2d = torch.bfloat16 if (bf16_input if bf16_input is not None else getattr(model, "accepts_bf16_input", False)) else torch.float32
         self.__dict__["_model"] = model
-        self.__dict__["_runner"] = _MicroBatchRunner(model, device, micro_batch, h2d, want_abs=True)
+        self.__dict__["_runner"] = _MicroBatchRunner(model, device, micro_batch, h2d, want_abs=True, pinned_direct=bf16_input is None)
         self.__dict__["_expect"] = None      # (device pointer of the yielded graph's x, its (abs, rel, edge_index))
         # The batched forwards run on a stream of their own: the loop's own device traffic (data.to(device) sends y and
         # edge_index of every graph, test.py:211) is ordered on the CURRENT stream and would otherwise queue behind the forward

@@ -197,8 +197,8 @@ def stem_conv_bn_relu_maxpool_bf16(x_nchw: torch.Tensor, wpack_bf16: torch.Tenso
     x_nchw, scale, shift = _req(x_nchw, "x_nchw", torch.bfloat16 if xbf else torch.float32), _req(scale, "scale"), _req(shift, "shift")
     wpack_bf16 = _req(wpack_bf16, "wpack_bf16", torch.bfloat16)
     n, c, h, w = x_nchw.shape
-    if c != 3 or tuple(wpack_bf16.shape) != (11, 2, 64, 8) or scale.numel() != 64 or shift.numel() != 64:
-        raise ValueError("expected x [N,3,H,W], wpack_bf16 [11,2,64,8], scale / shift [64]")
+    if c != 3 or wpack_bf16.numel() != (11 * 2 + 2 * 3 * 4) * 64 * 8 or scale.numel() != 64 or shift.numel() != 64:
+        raise ValueError("expected x [N,3,H,W], wpack_bf16 from params.pack_stem_bf16 (23,552 bf16), scale / shift [64]")
     hc, wc = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     hp, wp = (hc - 1) // 2 + 1, (wc - 1) // 2 + 1
     y = torch.empty((n, hp, wp, 64), dtype=torch.bfloat16, device=x_nchw.device)

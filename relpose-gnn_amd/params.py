@@ -128,7 +128,8 @@ def pack_resnet(sd: Dict[str, torch.Tensor], prefix: str = "feature_extractor.",
 
 
 def pack_stem_bf16(w_oihw: torch.Tensor) -> torch.Tensor:
-    """conv1.weight [64][3][7][7] -> wpack [11][2][64][8] bf16 of rpg_stem_conv7x7s2_bn_relu_maxpool_bf16: MFMA step s covers the
+    """conv1.weight [64][3][7][7] -> wpack bf16 of rpg_stem_conv7x7s2_bn_relu_maxpool_bf16, two operand images back to back
+    ([11][2][64][8] for the tile kernel, then [2][3][4][64][8] for the strip-march kernel).  Tile kernel: MFMA step s covers the
     (channel, kernel row) pairs 2s (lanes 0-31) and 2s + 1 (lanes 32-63), 8 kernel columns each (the 8th, and the 22nd pair, are
     zero); lane l of fragment nf holds output channel 32 nf + (l & 31).  Plain bf16 rounding (round-to-nearest-even), no scale
     folded in: like every other bf16 convolution the BatchNorm affine is applied in fp32 to the accumulators."""
@@ -137,7 +138,13 @@ def pack_stem_bf16(w_oihw: torch.Tensor) -> torch.Tensor:
     w = w_oihw.float().reshape(64, 21, 7)                                    # [ch][(c, kh)][kw]
     w = torch.nn.functional.pad(w, (0, 1, 0, 1))                             # [ch][22][8]: zero 8th column, zero 22nd row
     w = w.view(2, 32, 11, 2, 8)                                              # [nf][n][s][h][j]
-    return w.permute(2, 0, 3, 1, 4).reshape(11, 2, 64, 8).to(torch.bfloat16).contiguous()     # [s][nf][l = 32 h + n][j]
+    tile = w.permute(2, 0, 3, 1, 4).reshape(11 * 2 * 64 * 8)                 # [s][nf][l = 32 h + n][j]: the tile kernel (rounds 3-5)
+    # second part (round 6, the strip-march kernel): [nf][c][j][l = 32 h + n][t]: kernel rows 2 j + h of channel c (row 7: zeros),
+    # taps t = 0: zero, t = 1..7: kernel columns 0..6 -- the window of a pixel starts one input column to the left, at an even one
+    v = torch.nn.functional.pad(w_oihw.float(), (1, 0, 0, 1))                # [ch][c][8 kh][8 t]
+    v = v.view(2, 32, 3, 4, 2, 8)                                            # [nf][n][c][j][h][t]
+    strip = v.permute(0, 2, 3, 4, 1, 5).reshape(2 * 3 * 4 * 64 * 8)          # [nf][c][j][h][n][t]
+    return torch.cat([tile, strip]).to(torch.bfloat16).contiguous()
 
 
 def pack_resnet_bf16(sd: Dict[str, torch.Tensor], prefix: str = "feature_extractor.") -> Tuple[List[torch.Tensor], List[int], List[int]]:

@@ -370,16 +370,30 @@ def test_conv_bf16_lean_epilogue_equals_general(dev, n, h, w, cin, cout, k, stri
     assert float((got - ref).abs().mean() / ref.abs().mean().clamp(min=1e-30)) < 3e-3
 
 
+@pytest.mark.parametrize("kernel", [1, 5, 1 + (7 << 4), 1 + (14 << 4), 3])       # RPG_TUNE_FUSED_STEM: strip-march kernel (weights in LDS / in registers / 7-row bands), tile kernel
 @pytest.mark.parametrize("n,h,w", [(2, 224, 224), (1, 256, 341), (3, 37, 53), (2, 9, 5), (1, 64, 500), (5, 32, 40), (1, 1, 1), (70, 64, 72),
-                                   (67, 40, 24)])
-def test_fused_stem_bf16(dev, n, h, w):
+                                   (67, 40, 24), (2, 250, 123), (1, 30, 130)])
+def test_fused_stem_bf16(dev, n, h, w, kernel):
     """rpg_stem_conv7x7s2_bn_relu_maxpool_bf16 (fp32 NCHW in -> pooled bf16 NHWC out, bf16 MFMA) vs conv2d(7x7, s2, p3) on the
     SAME bf16-rounded input and weights in fp32 -> BN affine -> ReLU -> max_pool2d(3, 2, 1) -> bf16 (the torchvision stem
     reached from posenet.py:1037).  What is left between the two is fp32 summation order and, where that moves a value across a
     bf16 rounding boundary, one bf16 ulp (2^-8 relative) on single elements: bar 1e-2 max-norm like every bf16 convolution here,
     and the MEAN error must sit at the fp32-noise level (1e-4): a wrong tap or window would move every output.
     224x224 (two column tiles of 28), 256x341 (four ragged column tiles), odd / tiny sizes, a wide image (five column tiles), and
-    >= 64 images not a multiple of 8 (the per-XCD image order of the kernel, ragged)."""
+    >= 64 images not a multiple of 8 (the per-XCD image order of the kernel, ragged).
+    Round 6: the strip-march kernel (default; csrc/stem_bf16.hip stem_strip_bf16_kernel -- strips of 15 pooled columns, bands of 14
+    pooled rows: 224 -> 4 x 4, 341 wide -> 6 ragged strips, odd convolution heights (250 -> 125 rows: the last pooled row ends on
+    an even convolution row), images narrower than a strip) and the tile kernel of rounds 3-5 behind RPG_TUNE_FUSED_STEM = 3."""
+    from relpose_gnn_amd import ops
+    from relpose_gnn_amd.params import pack_stem_bf16
+    ops.set_tuning(ops.TUNE_FUSED_STEM, kernel)
+    try:
+        _fused_stem_bf16_case(dev, n, h, w)
+    finally:
+        ops.set_tuning(ops.TUNE_FUSED_STEM, 1)
+
+
+def _fused_stem_bf16_case(dev, n, h, w):
     from relpose_gnn_amd import ops
     from relpose_gnn_amd.params import pack_stem_bf16
     x = _rand(n, 3, h, w, seed=h)

@@ -429,6 +429,21 @@ def test_bf16_encoder_takes_host_rounded_bf16_images(dev):
         per_elt = {"bf16_staging": 2, "fp32_staging": 4, "resident": 0}[kind]
         assert st["h2d_bytes"] == per_elt * sum(sizes) * 3 * 32 * 40, (kind, st)
     assert np.array_equal(res["bf16_staging"], res["fp32_staging"]) and np.array_equal(res["resident"], res["fp32_staging"])
+    # round 6: fp32 images in PINNED memory (the reference's DataLoader(pin_memory=True), test.py:193) go to the device as they are
+    # -- no rounding pass, no staging copy -- unless the caller forces the rounding (bf16_input=True); a stream that mixes pinned and
+    # pageable micro-batches uses both pipelines; the poses never change
+    pinned = [Data(x=g.x.clone().pin_memory(), edge_index=g.edge_index, y=g.y) for g in graphs]
+    total = sum(sizes) * 3 * 32 * 40
+    for kind, gs, flag, want in (("pinned_auto", pinned, None, (4 * total, 0, 4 * total)), ("pinned_forced_bf16", pinned, True, (2 * total, 2 * total, 0)),
+                                 ("pinned_then_pageable", pinned[:3] + graphs[3:], None, None)):
+        st = {}
+        got = E.evaluate_stream(m, gs, dev, micro_batch=3, stats=st, bf16_input=flag).pred_poses
+        assert np.array_equal(got, res["fp32_staging"]), kind
+        if want is not None:
+            assert (st["h2d_bytes"], st["staged_bytes"], st["direct_bytes"]) == want, (kind, st)
+        else:
+            first = sum(sizes[:3]) * 3 * 32 * 40
+            assert st["direct_bytes"] == 4 * first and st["staged_bytes"] == 2 * (total - first), (kind, st)
     # RPG_TUNE_FUSED_STEM = 0: the three-kernel stem takes the host-rounded bf16 images too -- a tuning knob must
     # not turn a working evaluation loop into an error -- and agrees with its own fp32-input run bit for bit
     from relpose_gnn_amd import ops
