@@ -326,14 +326,18 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
 #define RPG_TUNE_WAVES8 11        /* 1: 8-wave workgroups (two waves per SIMD) for the 128x128 / 128x64 tiles of the f32 tile engine where
                                      the buffer-load path applies (default) | 0: always 4-wave workgroups */
 #define RPG_TUNE_FUSED_STEM 10    /* bit 0: one-kernel stem (conv7x7 + BN + ReLU + max-pool) where its operands are given (default 1) | 0: three kernels.
-                                     bf16 stem only: bit 1 = the tile kernel of rounds 3-5 instead of the strip-march kernel of round 6; bit 2 = the
-                                     strip-march kernel keeps its weights in registers (two waves per SIMD) instead of LDS (three); value >> 4 =
-                                     pooled rows per band of the strip-march kernel (0, the default: by the launch's size) */
+                                     bf16 stem only: bit 1 = the tile kernel of rounds 3-5 instead of the strip-march kernel of round 6; variants of the
+                                     strip-march kernel (none of these bits: the default, bit 3): bit 3 = both 32-channel halves in one wave, weights in
+                                     LDS, two waves per SIMD; bit 5 = one half per wave, weights in LDS, three waves per SIMD; bit 2 = one half per wave,
+                                     weights in registers, two waves; bit 4 = one half per wave, four waves per SIMD; value >> 8 = pooled rows per band
+                                     (0, the default: by the launch's size) */
 #define RPG_TUNE_WINO_SPLIT 8     /* 1: split-K tail + fix-up for the 8-wave Winograd kernel (default) | 0: whole tiles only | n >= 2: as 1, and a part of a
                                      tile gets at least n K steps in the one-workgroup-per-tile form (default 3: one 8-node graph 1.50 ms per forward, 1.63 with 4) */
 #define RPG_TUNE_FAST_LOADER 7    /* 1: buffer-load loaders + interleaved main loop where eligible (default) | 0: general loaders */
 #define RPG_TUNE_WINOGRAD 4       /* 0: always the direct kernel | 1: use u_wino43 where given, kernel by size (default) |
-                                     2 / 3: as 1 but always the 4-wave single-image / the 8-wave Winograd kernel */
+                                     2 / 3: as 1 but always the 4-wave single-image / the 8-wave Winograd kernel | n >= 16: as 1 with the
+                                     Winograd kernels from n blocks of 64 tiles x 64 channels per layer up (default 16; larger: the small layers of
+                                     a small batch go to the direct kernel, which reads half the weight bytes) */
 #define RPG_TUNE_WINO_SHORT 12    /* retired in round 3 with the short-K Winograd kernel it selected (measured: no gain); the key is
                                      still accepted (values >= 0) and ignored */
 #define RPG_TUNE_WINO_PERSIST 14  /* 1: launches with more 8-wave tiles than CUs run the persistent kernel (one workgroup per CU walks its

@@ -274,13 +274,15 @@ struct StemSArgs {
     __bf16* out;
     int N, H, W, Hc, Wc, Hp, Wp;
     int TP, tiles_x, BH, bands;
-    unsigned items;        // N * bands * tiles_x * 2
+    unsigned items;        // N * bands * tiles_x * (2 / NF)
 };
 
 // WLDS: the weights live in LDS (24 KB per workgroup, one ds_read_b128 per MFMA) and the kernel fits three waves per SIMD;
 // !WLDS: in registers (48 VGPRs), two waves per SIMD.
-template <typename TIn, bool WLDS>
-__global__ __launch_bounds__(SS_NT) __attribute__((amdgpu_waves_per_eu(WLDS ? 3 : 2, WLDS ? 3 : 2))) void stem_strip_bf16_kernel(StemSArgs a) {
+// NF: 32-channel halves per wave (1: two work items per strip, three waves per SIMD with the weights in LDS; 2: one item per strip --
+// half the input loads and conversions per MFMA, two accumulator chains, two waves per SIMD).
+template <typename TIn, bool WLDS, int NF, int WPE = ((WLDS && NF == 1) ? 3 : 2)>
+__global__ __launch_bounds__(SS_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void stem_strip_bf16_kernel(StemSArgs a) {
     constexpr int ESZ = (int)sizeof(TIn);
     constexpr int NLD = ESZ == 4 ? 2 : 1;                 // 16-byte loads per 8-column window
     constexpr unsigned SENT = 0x80000000u;
@@ -300,8 +302,8 @@ __global__ __launch_bounds__(SS_NT) __attribute__((amdgpu_waves_per_eu(WLDS ? 3 
     if ((nb & 15u) == 0) { const unsigned xcd = b & 7u, k = b >> 3; wg = ((k >> 1) * 8u + xcd) * 2u + (k & 1u); }
     const unsigned item = wg * 4u + (unsigned)wave;
     if (item >= a.items) return;
-    const int nf = (int)(item & 1u);
-    unsigned rest = item >> 1;
+    const int nf = NF == 1 ? (int)(item & 1u) : 0;        // first 32-channel half of this wave
+    unsigned rest = NF == 1 ? item >> 1 : item;
     const int strip = (int)(rest % (unsigned)a.tiles_x); rest /= (unsigned)a.tiles_x;
     const int band = (int)(rest % (unsigned)a.bands);
     const int n = (int)(rest / (unsigned)a.bands);
@@ -339,6 +341,7 @@ __global__ __launch_bounds__(SS_NT) __attribute__((amdgpu_waves_per_eu(WLDS ? 3 
                                                                                      //  of the next image / of the allocation's padding)
 
     // ---- weights: A operands, resident
+    static_assert(WLDS || NF == 1, "register weights: one 32-channel half per wave");
     bf16x8 wreg[WLDS ? 1 : 3][WLDS ? 1 : 4];
     if constexpr (!WLDS) {
 #pragma unroll
@@ -347,9 +350,9 @@ __global__ __launch_bounds__(SS_NT) __attribute__((amdgpu_waves_per_eu(WLDS ? 3 
             for (int j = 0; j < 4; ++j) wreg[c][j] = __builtin_bit_cast(bf16x8, a.wpack[((nf * 3 + c) * 4 + j) * 64 + lane]);
     }
     const uint4* const wl_lane = wl + (WLDS ? nf * 12 * 64 + lane : 0);
-    auto weight = [&](int c, int j) -> bf16x8 {
-        if constexpr (WLDS) return __builtin_bit_cast(bf16x8, wl_lane[(c * 4 + j) * 64]);
-        else return wreg[c][j];
+    auto weight = [&](int f, int k) -> bf16x8 {           // fragment of half nf + f, MFMA k = 4 c + j
+        if constexpr (WLDS) return __builtin_bit_cast(bf16x8, wl_lane[(f * 12 + k) * 64]);
+        else return wreg[k / 4][k % 4];
     };
 
     bf16x8 op[3][4];                                      // pixel operands; logical pair j of row oy lives in slot (j + oy) & 3
@@ -406,9 +409,11 @@ __global__ __launch_bounds__(SS_NT) __attribute__((amdgpu_waves_per_eu(WLDS ? 3 
     };
 
     typedef unsigned u32;
-    u32 mx[8];                                            // running maximum of the pooled row in progress: bf16 pairs, >= +0
+    u32 mx[NF][8];                                        // running maximum of the pooled row in progress: bf16 pairs, >= +0
 #pragma unroll
-    for (int i = 0; i < 8; ++i) mx[i] = 0u;
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mx[f][i] = 0u;
     auto pk_max = [](u32 x, u32 y) -> u32 {
         typedef short s16x2 __attribute__((ext_vector_type(2)));
         return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2, x), __builtin_bit_cast(s16x2, y)));
@@ -416,19 +421,22 @@ __global__ __launch_bounds__(SS_NT) __attribute__((amdgpu_waves_per_eu(WLDS ? 3 
     __bf16* const out_n = a.out + (size_t)n * a.Hp * a.Wp * 64 + 32 * nf + 4 * h;
     auto emit = [&](int py) {                             // horizontal 3-maximum + store of pooled row py (lanes l < nq hold column Q0 + l)
         if (py < P0 || py >= P0 + np) return;
-        u32 r[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const u32 right = (u32)__builtin_amdgcn_update_dpp(0, (int)mx[i], 0x101, 0xf, 0xf, true);       // row_shl:1: lane i <- lane i + 1
-            const u32 odd = (u32)__builtin_amdgcn_ds_swizzle((int)mx[i], 0x401f);                            // lane i <- lane i ^ 16
-            r[i] = pk_max(pk_max(mx[i], right), odd);
-        }
-        if (l < nq) {
-            __bf16* o = out_n + ((size_t)py * a.Wp + Q0 + l) * 64;
+        for (int f = 0; f < NF; ++f) {
+            u32 r[8];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 v; v.x = r[2 * g]; v.y = r[2 * g + 1];
-                *reinterpret_cast<uint2*>(o + 8 * g) = v;
+            for (int i = 0; i < 8; ++i) {
+                const u32 right = (u32)__builtin_amdgcn_update_dpp(0, (int)mx[f][i], 0x101, 0xf, 0xf, true);       // row_shl:1: lane i <- lane i + 1
+                const u32 odd = (u32)__builtin_amdgcn_ds_swizzle((int)mx[f][i], 0x401f);                            // lane i <- lane i ^ 16
+                r[i] = pk_max(pk_max(mx[f][i], right), odd);
+            }
+            if (l < nq) {
+                __bf16* o = out_n + ((size_t)py * a.Wp + Q0 + l) * 64 + 32 * f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 v; v.x = r[2 * g]; v.y = r[2 * g + 1];
+                    *reinterpret_cast<uint2*>(o + 8 * g) = v;
+                }
             }
         }
     };
@@ -441,35 +449,42 @@ __global__ __launch_bounds__(SS_NT) __attribute__((amdgpu_waves_per_eu(WLDS ? 3 
     // MFMA k = 4 c + j; the weight fragment of MFMA k + 2 is read behind MFMA k (three fragment registers in rotation).
 #define RPG_SS_MFMA(K, R)                                                                                                      \
     do {                                                                                                                       \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WLDS ? wf[(K) % 3] : wreg[WLDS ? 0 : (K) / 4][WLDS ? 0 : (K) % 4],       \
-                                                      op[(K) / 4][(((K) % 4) + (R)) & 3], acc, 0, 0, 0);                       \
-        if (WLDS && (K) + 2 < 12) wf[((K) + 2) % 3] = weight(((K) + 2) / 4, ((K) + 2) % 4);                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                                       \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WLDS ? wf[f][(K) % 3] : wreg[WLDS ? 0 : (K) / 4][WLDS ? 0 : (K) % 4], \
+                                                             op[(K) / 4][(((K) % 4) + (R)) & 3], acc[f], 0, 0, 0);             \
+            if (WLDS && (K) + 2 < 12) wf[f][((K) + 2) % 3] = weight(f, (K) + 2);                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        }                                                                                                                      \
     } while (0)
 #define RPG_SS_ROW(R)                                                                                                          \
     do {                                                                                                                       \
         _Pragma("unroll") for (int c = 0; c < 3; ++c) op[c][(3 + (R)) & 3] = pack_pair(c, oy);                                 \
         issue(oy + 1);         /* (past the last row too: range-checked, never used) */                                        \
         if (oy >= oy_first) {                                                                                                  \
-            f32x16 acc;                                                                                                        \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[e] = 0.f;                                                       \
-            bf16x8 wf[3];                                                                                                      \
-            if (WLDS) { wf[0] = weight(0, 0); wf[1] = weight(0, 1); }                                                          \
+            f32x16 acc[NF];                                                                                                    \
+            bf16x8 wf[NF][3];                                                                                                  \
+            _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                                   \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;                                                \
+                if (WLDS) { wf[f][0] = weight(f, 0); wf[f][1] = weight(f, 1); }                                                \
+            }                                                                                                                  \
             __builtin_amdgcn_sched_barrier(0);                                                                                 \
             RPG_SS_MFMA(0, R); RPG_SS_MFMA(1, R); RPG_SS_MFMA(2, R); RPG_SS_MFMA(3, R);                                        \
             RPG_SS_MFMA(4, R); RPG_SS_MFMA(5, R); RPG_SS_MFMA(6, R); RPG_SS_MFMA(7, R);                                        \
             RPG_SS_MFMA(8, R); RPG_SS_MFMA(9, R); RPG_SS_MFMA(10, R); RPG_SS_MFMA(11, R);                                      \
-            u32 pv[8];                                                                                                         \
-            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                    \
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(aff + 32 * nf + 8 * g + 4 * h);                               \
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(aff + 64 + 32 * nf + 8 * g + 4 * h);                          \
-                pv[2 * g] = pk2_bf16(fmaf(acc[4 * g + 0], sc[0], sh[0]), fmaf(acc[4 * g + 1], sc[1], sh[1]));                  \
-                pv[2 * g + 1] = pk2_bf16(fmaf(acc[4 * g + 2], sc[2], sh[2]), fmaf(acc[4 * g + 3], sc[3], sh[3]));              \
+            u32 pv[NF][8];                                                                                                     \
+            _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                                   \
+                _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                \
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(aff + 32 * (nf + f) + 8 * g + 4 * h);                     \
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(aff + 64 + 32 * (nf + f) + 8 * g + 4 * h);                \
+                    pv[f][2 * g] = pk2_bf16(fmaf(acc[f][4 * g + 0], sc[0], sh[0]), fmaf(acc[f][4 * g + 1], sc[1], sh[1]));     \
+                    pv[f][2 * g + 1] = pk2_bf16(fmaf(acc[f][4 * g + 2], sc[2], sh[2]), fmaf(acc[f][4 * g + 3], sc[3], sh[3])); \
+                }                                                                                                              \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) mx[f][i] = pk_max(mx[f][i], pv[f][i]);                           \
             }                                                                                                                  \
-            _Pragma("unroll") for (int i = 0; i < 8; ++i) mx[i] = pk_max(mx[i], pv[i]);                                        \
             if ((R) & 1) {                                                                                                     \
                 emit((oy - 1) >> 1);                                                                                           \
-                _Pragma("unroll") for (int i = 0; i < 8; ++i) mx[i] = pk_max(pv[i], 0u);                                       \
+                _Pragma("unroll") for (int f = 0; f < NF; ++f)                                                                 \
+                    _Pragma("unroll") for (int i = 0; i < 8; ++i) mx[f][i] = pk_max(pv[f][i], 0u);                             \
             }                                                                                                                  \
         }                                                                                                                      \
         ++oy;                                                                                                                  \
@@ -517,7 +532,10 @@ static bool stem_pool_bf16_geometry(int n, int h, int w, StemBArgs& a, int& grid
     return (long)((long)n / a.nxcd + 1 + grid) * a.tiles_y * a.tiles_x * a.tiles_y * a.tiles_x < (1L << 32);
 }
 
-int g_stem_strip = 1;          // 0: the tile kernel (rounds 3-5) | 1: the strip-march kernel of round 6, weights in LDS | 5: weights in registers
+int g_stem_strip = 9;          // 0: the tile kernel (rounds 3-5) | bit 0: the strip-march kernel of round 6, + bit 3 (default): both 32-channel halves in
+                               // one wave (measured at 512 images, profiles/r6_stem_bf16_variants.txt: 227 us against 255-265 with one half per wave
+                               // and three waves per SIMD -- the texture addresser was 72 % busy with every input window loaded by two waves --,
+                               // 264 with the weights in registers (bit 2), 260 with four waves per SIMD (bit 4), 375 for the tile kernel)
 int g_stem_strip_bh = 0;       // pooled rows per band (RPG_TUNE_FUSED_STEM value >> 4, experiments); 0 = by the launch's size
 void bf16_set_stem_strip(int mode, int bh) { g_stem_strip = mode; g_stem_strip_bh = bh > 0 ? bh : 0; }
 
@@ -535,11 +553,11 @@ static bool stem_strip_geometry(int n, int h, int w, int esz, StemSArgs& a, int&
         // pooled rows, 270 with 4 of 14, 283 with 8 of 7), short ones fill the chip when there are few images: the fewest bands that
         // still give two rounds of workgroups (768 resident: 256 CUs x 3), never shorter than 7 pooled rows
         int bands = 1;
-        while ((long)n * bands * a.tiles_x * 2 / 4 < 2 * 3L * num_cus() && (a.Hp + 2 * bands - 1) / (2 * bands) >= 7) bands *= 2;
+        while ((long)n * bands * a.tiles_x * (g_stem_strip & 8 ? 1 : 2) / 4 < 2 * (g_stem_strip & 8 ? 2L : (g_stem_strip & 16 ? 4L : 3L)) * num_cus() && (a.Hp + 2 * bands - 1) / (2 * bands) >= 7) bands *= 2;
         a.BH = (a.Hp + bands - 1) / bands;
     }
     a.bands = (a.Hp + a.BH - 1) / a.BH;
-    const long items = (long)n * a.bands * a.tiles_x * 2;
+    const long items = (long)n * a.bands * a.tiles_x * (g_stem_strip & 8 ? 1 : 2);        // bit 3: both channel halves in one wave
     // 32-bit byte offsets inside an image (incl. the rows read past its ends), 32-bit item index
     if ((long)3 * h * w * esz + (long)16 * w * esz >= (1L << 31) || items + 64 >= (1L << 32)) return false;
     a.items = (unsigned)items;
@@ -565,12 +583,18 @@ int launch_stem_pool_bf16(const void* x_nchw, int x_is_bf16, const void* wpack, 
             sa.x = x_nchw; sa.scale = scale; sa.shift = shift; sa.out = reinterpret_cast<__bf16*>(out);
             sa.wpack = reinterpret_cast<const uint4*>(wpack) + KS * NF * 64;       // second part of params.pack_stem_bf16
             const int slot = timing_begin(RPG_TIMER_CONV, s);
-            if (g_stem_strip & 4) {
-                if (x_is_bf16) hipLaunchKernelGGL((stem_strip_bf16_kernel<__bf16, false>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
-                else hipLaunchKernelGGL((stem_strip_bf16_kernel<float, false>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+            if (g_stem_strip & 16) {
+                if (x_is_bf16) hipLaunchKernelGGL((stem_strip_bf16_kernel<__bf16, true, 1, 4>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+                else hipLaunchKernelGGL((stem_strip_bf16_kernel<float, true, 1, 4>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+            } else if (g_stem_strip & 8) {
+                if (x_is_bf16) hipLaunchKernelGGL((stem_strip_bf16_kernel<__bf16, true, 2>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+                else hipLaunchKernelGGL((stem_strip_bf16_kernel<float, true, 2>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+            } else if (g_stem_strip & 4) {
+                if (x_is_bf16) hipLaunchKernelGGL((stem_strip_bf16_kernel<__bf16, false, 1>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+                else hipLaunchKernelGGL((stem_strip_bf16_kernel<float, false, 1>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
             } else {
-                if (x_is_bf16) hipLaunchKernelGGL((stem_strip_bf16_kernel<__bf16, true>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
-                else hipLaunchKernelGGL((stem_strip_bf16_kernel<float, true>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+                if (x_is_bf16) hipLaunchKernelGGL((stem_strip_bf16_kernel<__bf16, true, 1>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+                else hipLaunchKernelGGL((stem_strip_bf16_kernel<float, true, 1>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
             }
             // executed: per item 2 np + 1 convolution rows x 12 MFMAs of 32 x 32 x 16
             timing_end(slot, 2.0 * (double)n * sa.Hc * sa.Wc * 64.0 * 147.0, s,

@@ -1153,6 +1153,7 @@ int g_wino_split_steps = 3;              // ... and the least number of K steps 
                                          // one 8-node graph, r3: 4 -> 1.63 ms per forward, 3 or 2 -> 1.50; 6 -> 1.61; the benched 32-graph launches do not get here:
                                          // their part count is bound by CUs / tail tiles)
 int g_wino = 1;                          // RPG_TUNE_WINOGRAD: 0 off | 1 auto | 2 / 3: always the 4-wave / 8-wave kernel
+int g_wino_min_blocks = 16;              // ... | n >= 16: auto, Winograd from n blocks of 64 tiles x 64 channels up (default 16; round 6: the per-layer rule of small batches)
 int g_wino_persist = 1;                  // RPG_TUNE_WINO_PERSIST: the persistent 8-wave kernel when a launch has more tiles than CUs
 int g_wino_combine_max = 8;              // most parts of a tail tile that its last-arriving workgroup adds up itself (one CU reads parts x 128 KB:
                                          // beyond this the 32-blocks-per-tile fix-up launch is the faster way); RPG_TUNE_INKERNEL_FIXUP >= 2 sets it
@@ -1169,7 +1170,7 @@ namespace rpg {
 void wino2d_set(int) {}                           // RPG_TUNE_WINO2D is accepted (0) and ignored in a build without the probe kernel
 #endif
 bool wino_enabled() { return g_wino != 0; }
-void wino_set(int on) { g_wino = on; }
+void wino_set(int on) { if (on >= 16) { g_wino = 1; g_wino_min_blocks = on; } else { g_wino = on; g_wino_min_blocks = 16; } }
 void wino_split_set(int v) { g_wino_split = v != 0; g_wino_split_steps = v >= 2 ? v : 3; }
 void wino_short_set(int) {}              // RPG_TUNE_WINO_SHORT: retired with the short-K kernel (accepted, ignored)
 void wino_persist_set(int on) { g_wino_persist = on; }      // 2: also for launches of at most one tile per CU
@@ -1184,7 +1185,7 @@ bool wino_pays(int n, int h, int w, int cin, int cout) {
     const long tiles = (long)n * h * ((w + 3) / 4);
     const long blocks = ((tiles + BMT - 1) / BMT) * ((cout + BN - 1) / BN);
     const int tw = (w + 3) / 4;
-    return blocks >= 16 && (long)h * w * cin * 4 * 67 < (1L << 31) && 6L * cout * 3 * cin * 4 < (1L << 31) &&
+    return blocks >= g_wino_min_blocks && (long)h * w * cin * 4 * 67 < (1L << 31) && 6L * cout * 3 * cin * 4 < (1L << 31) &&
            (32L / tw + 3) * w * cout * 4 < (1L << 31);
 }
 

@@ -243,8 +243,8 @@ class _MicroBatchRunner:
                 "staging_workers": max((p.workers for p in ps), default=0)}
 
     def launch(self, chunk: Sequence[Data]):
-        """-> (chunk, host_rel, host_ei | None, ev | None, host_abs | None, x_dev): x_dev = the chunk's node images as the
-        forward read them (rows in chunk order)."""
+        """-> (chunk, host_rel, host_ei | None, ev | None, host_abs | None, batch): batch = the collated micro-batch the forward
+        read (batch.x: the chunk's node images, rows in chunk order; batch.edge_index: batch node ids)."""
         device, model = self.device, self.model
         k = self.n_batches & 1
         self.n_batches += 1
@@ -293,7 +293,7 @@ class _MicroBatchRunner:
         else:
             host, host_ei, ev = rel, (edge_index if model_built else None), None
             host_abs = ab if self.want_abs else None
-        return chunk, host, host_ei, ev, host_abs, batch.x
+        return chunk, host, host_ei, ev, host_abs, batch
 
 
 def edges_per_graph(ei: np.ndarray, sizes: Sequence[int]):

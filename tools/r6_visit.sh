@@ -1,7 +1,5 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6b; mkdir -p $OUT
-timeout 1200 python -m pytest tests/test_hip_bf16.py tests/test_hip_model.py tests/test_hip_eval_geometry.py tests/test_hip_bench_geometry.py -q -m gpu -x > $OUT/pytest_bf16.log 2>&1; echo "rc=$?" >> $OUT/pytest_bf16.log; tail -15 $OUT/pytest_bf16.log
-#timeout 300 python tools/stem_bench.py 512 --bf16 > $OUT/stem_bench.txt 2>&1; grep -v amdgpu.ids $OUT/stem_bench.txt | head -6
-#timeout 300 python tools/stem_bench.py 512 --bf16 --shape 256x341 > $OUT/stem_bench_341.txt 2>&1; grep -v amdgpu.ids $OUT/stem_bench_341.txt | head -6
-#timeout 300 python tools/stem_bench.py 64 --bf16 > $OUT/stem_bench_64.txt 2>&1; grep -v amdgpu.ids $OUT/stem_bench_64.txt | head -4
-#timeout 300 python tools/stem_bench.py 8 --bf16 > $OUT/stem_bench_8.txt 2>&1; grep -v amdgpu.ids $OUT/stem_bench_8.txt | head -4
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6f; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_hip_bf16.py tests/test_hip_model.py -q -m gpu -x -k "fused_stem or lookahead or reference_eval_loop or pipeline or host_rounded" > $OUT/pytest.log 2>&1; echo "rc=$?" >> $OUT/pytest.log; tail -4 $OUT/pytest.log
+timeout 600 python tools/lookahead_probe.py > $OUT/lookahead_probe.txt 2>&1; grep -v amdgpu.ids $OUT/lookahead_probe.txt
+timeout 300 python tools/stem_bench.py 512 --bf16 --variants default > $OUT/stem_bench.txt 2>&1; grep -v amdgpu.ids $OUT/stem_bench.txt

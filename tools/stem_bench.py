@@ -11,7 +11,8 @@ from relpose_gnn_amd import ops  # noqa: E402
 from relpose_gnn_amd.params import pack_stem_bf16, pack_stem_pairs  # noqa: E402
 
 dev = torch.device("cuda:0")
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+_vals = {sys.argv[i + 1] for i, a in enumerate(sys.argv) if a in ("--shape", "--variants") and i + 1 < len(sys.argv)}
+args = [a for a in sys.argv[1:] if not a.startswith("--") and a not in _vals]
 shape = next((sys.argv[i + 1] for i, a in enumerate(sys.argv) if a == "--shape"), "224x224")
 h, w = (int(v) for v in shape.split("x"))
 bf16 = "--bf16" in sys.argv
@@ -44,8 +45,12 @@ else:
     wp = pack_stem_bf16(wt).to(dev)
     sc, sh = torch.rand(64, device=dev) + 0.5, torch.zeros(64, device=dev)
     xb = x.bfloat16()
-    for name, val in (("tile kernel (r3-r5)", 3), ("strips, default", 1), ("strips, weights in LDS, bands of 14", 1 + (14 << 4)), ("strips, weights in registers, 14", 5 + (14 << 4)),
-                      ("strips, LDS, bands of 7", 1 + (7 << 4)), ("strips, LDS, bands of 28", 1 + (28 << 4)), ("strips, regs, bands of 7", 5 + (7 << 4))):
+    only = next((sys.argv[i + 1] for i, a in enumerate(sys.argv) if a == "--variants"), "")
+    for name, val in (("tile kernel (r3-r5)", 3), ("strips, default (both halves per wave)", 1), ("strips, one half per wave, LDS weights, 3 waves/SIMD", 33),
+                      ("strips, one half, register weights", 5), ("strips, one half, 4 waves/SIMD", 17), ("strips, default, bands of 14", 1 + (14 << 8)),
+                      ("strips, default, bands of 56", 1 + (56 << 8))):
+        if only and only not in name:
+            continue
         ops.set_tuning(ops.TUNE_FUSED_STEM, val)
         for xin, tag in ((x, "fp32 in"), (xb, "bf16 in")):
             med, best = timeit(lambda: ops.stem_conv_bn_relu_maxpool_bf16(xin, wp, sc, sh))
