@@ -396,6 +396,9 @@ int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
                                      GNN's edge GEMMs: M = 56 edges x graphs = 7 * 2^k rows): bit 0 = the exact-fit kernel on v_mfma_f32_16x16x4_f32
                                      (no stream-K split, no fix-up launch), bit 1 = its eight-wave form (the two k halves of a step on two wave
                                      groups) for launches of about one tile per CU; default 3; 0 = the 32x32x2 tile engine */
+#define RPG_TUNE_FIXUP_PRIO 30       /* experiment of round 6, OFF by default: 1 = the fix-up launches of split tiles (Winograd tail, stream-K) run on a
+                                     high-priority companion of the launch stream (event hand-off there and back), so that under two concurrent
+                                     streams they are dispatched ahead of the other stream's queued convolution workgroups */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

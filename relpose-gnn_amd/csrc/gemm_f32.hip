@@ -154,6 +154,49 @@ float* get_scratch(hipStream_t s, size_t bytes, unsigned** counters = nullptr) {
     if (counters) *counters = reinterpret_cast<unsigned*>(sc.p);
     return sc.p + kCounterBytes / sizeof(float);
 }
+// RPG_TUNE_FIXUP_PRIO (round 6 experiment): the fix-up launches of split tiles (Winograd tail, stream-K) go to a
+// HIGH-PRIORITY companion of the launch stream -- event hand-off there and back -- so that, with two batch halves on two streams,
+// a 6-us fix-up is dispatched ahead of the other stream's queued convolution workgroups instead of behind them (measured r5:
+// 22 us per Winograd fix-up under two streams against 6 alone).  One companion (stream + two events) per (device, stream), created
+// on first use outside of any capture; never freed (streams are few and live as long as the process).
+int g_fixup_prio = 0;
+struct Companion { hipStream_t hi = nullptr; hipEvent_t there = nullptr, back = nullptr; };
+std::map<std::pair<int, hipStream_t>, Companion> g_companion;
+hipStream_t fixup_hop_begin_impl(hipStream_t s) {
+    if (!g_fixup_prio) return s;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Companion* c;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        c = &g_companion[{dev, s}];
+        if (!c->hi) {
+            int lo = 0, hi = 0;                                                        // (numerically lowest = greatest priority)
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); return s; }
+            if (hipStreamCreateWithPriority(&c->hi, hipStreamNonBlocking, hi) != hipSuccess ||
+                hipEventCreateWithFlags(&c->there, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->back, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                c->hi = nullptr;
+                return s;
+            }
+        }
+    }
+    if (hipEventRecord(c->there, s) != hipSuccess || hipStreamWaitEvent(c->hi, c->there, 0) != hipSuccess) { (void)hipGetLastError(); return s; }
+    return c->hi;
+}
+void fixup_hop_end_impl(hipStream_t s, hipStream_t used) {
+    if (used == s) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Companion c;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        c = g_companion[{dev, s}];
+    }
+    (void)hipEventRecord(c.back, used);
+    (void)hipStreamWaitEvent(s, c.back, 0);
+}
 int g_inkernel_fixup = 0;            // RPG_TUNE_INKERNEL_FIXUP (bit 0: stream-K, bit 1: Winograd): partial tiles combined by the last-arriving
                                      // workgroup instead of a fix-up launch.  OFF by default: measured slower
 
@@ -581,6 +624,8 @@ namespace rpg {
 bool gnn_split_enabled() { return g_gnn_split != 0; }
 bool gnn_fuse_agg_enabled() { return g_gnn_fuse_agg != 0; }
 float* stream_scratch(hipStream_t s, size_t bytes, unsigned** counters) { return get_scratch(s, bytes, counters); }
+hipStream_t fixup_hop_begin(hipStream_t s) { return fixup_hop_begin_impl(s); }
+void fixup_hop_end(hipStream_t s, hipStream_t used) { fixup_hop_end_impl(s, used); }
 bool inkernel_fixup_enabled() { return (g_inkernel_fixup & 2) != 0; }      // (the Winograd launcher asks)
 ScratchScope::ScratchScope(void* p, size_t bytes, hipStream_t s) {
     // the arrival counters at the head of the slice must be zero when the first split launch of this call starts: the
@@ -724,6 +769,7 @@ extern "C" int rpg_release_scratch(void) {
 
 extern "C" int rpg_set_tuning(int key, int value) {
     switch (key) {
+        case RPG_TUNE_FIXUP_PRIO: g_fixup_prio = value != 0; return RPG_OK;
         case RPG_TUNE_TILE: g_force_tile = value; return RPG_OK;
         case RPG_TUNE_BK: if (value != 0 && value != 16 && value != 32) return RPG_ERR_BAD_ARG; g_bk = value; return RPG_OK;
         case RPG_TUNE_EPILOGUE: g_epi_lds = value != 0; return RPG_OK;

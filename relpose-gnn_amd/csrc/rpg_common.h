@@ -62,6 +62,10 @@ constexpr size_t kWorkspaceSkew = 260 * 1024 + 4096;
 // counters (optional out): the block's arrival counters -- 4096 unsigned, zero between launches (see gemm_f32.hip) -- for the
 // in-kernel combine of split tiles by the last-arriving workgroup
 float* stream_scratch(hipStream_t s, size_t bytes, unsigned** counters = nullptr);
+// RPG_TUNE_FIXUP_PRIO: the stream a split tile's fix-up launch goes to (s itself when off; else the high-priority companion of s,
+// already waiting for what s has enqueued) and the hand-back (s waits for the companion)
+hipStream_t fixup_hop_begin(hipStream_t s);
+void fixup_hop_end(hipStream_t s, hipStream_t used);
 bool inkernel_fixup_enabled();            // RPG_TUNE_INKERNEL_FIXUP bit 1 (Winograd tail tiles); OFF by default (measured slower)
 struct ScratchScope {
     ScratchScope(void* p, size_t bytes, hipStream_t s);       // zeroes the slice's counter header on s (one memset node per call)

@@ -1260,9 +1260,12 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
             const long items = sp.n_split + t_main;
             hipLaunchKernelGGL(wino43_conv8p_kernel, dim3((unsigned)(items < S ? items : S)), dim3(NT8), LDS8_BYTES, s, x, u, h, w,
                                cin, cout, tw, (int)M, ep, tn, sp, (int)items);
-            if (sp.n_split)
-                hipLaunchKernelGGL(wino43_fixup_kernel, dim3((unsigned)(T - t_main) * 32), dim3(256), 0, s, sp.partial, ep, (int)M,
+            if (sp.n_split) {
+                hipStream_t fs = fixup_hop_begin(s);                                     // RPG_TUNE_FIXUP_PRIO: high-priority companion stream
+                hipLaunchKernelGGL(wino43_fixup_kernel, dim3((unsigned)(T - t_main) * 32), dim3(256), 0, fs, sp.partial, ep, (int)M,
                                    tw, w, cout, tn, sp);
+                fixup_hop_end(s, fs);
+            }
             timing_end(slot, 2.0 * (double)n * h * w * cout * 9.0 * cin, s, executed);
             RPG_CHECK_LAUNCH("conv3x3_wino43");
             return RPG_OK;
@@ -1281,9 +1284,12 @@ int launch_conv_wino(const float* x, const float* u, const float* scale, const f
         // one launch: the split workgroups first, then the whole tiles
         hipLaunchKernelGGL(wino43_conv8_kernel, dim3((unsigned)(sp.n_split + t_main)), dim3(NT8), LDS8_BYTES, s, x, u, h, w, cin,
                            cout, tw, (int)M, ep, tn, sp);
-        if (sp.n_split && !sp.arrive)
-            hipLaunchKernelGGL(wino43_fixup_kernel, dim3((unsigned)(T - t_main) * 32), dim3(256), 0, s, sp.partial, ep, (int)M, tw, w,
+        if (sp.n_split && !sp.arrive) {
+            hipStream_t fs = fixup_hop_begin(s);
+            hipLaunchKernelGGL(wino43_fixup_kernel, dim3((unsigned)(T - t_main) * 32), dim3(256), 0, fs, sp.partial, ep, (int)M, tw, w,
                                cout, tn, sp);
+            fixup_hop_end(s, fs);
+        }
     } else {
         const int tm = (int)((M + BMT - 1) / BMT);
         executed = (double)tm * tn * (3 * ((cin + BK - 1) / BK)) * 48.0 * 4.0 * 4096.0;
