@@ -272,8 +272,10 @@ int rpg_gnn_forward_bf16(const float* const* tensors, int n_tensors, const void*
  * [64][3][3][64] (OHWI), folded BatchNorm scale / shift fp32 [64] (16-byte aligned).  Replaces the two aten conv2d + batch_norm +
  * relu (+ add) sequences of torchvision's BasicBlock.forward (reference call site: modules/posenet.py:1037) for ResNet34's
  * layer 1.  The intermediate activation is rounded to bf16 exactly where the two-launch path stores it: outputs are bit-identical
- * to rpg_conv2d_bn_act_nhwc_bf16 called twice.  Maps up to 63 pixels wide; RPG_ERR_BAD_ARG for shapes it does not take (the
- * caller then uses two convolution calls).  No workspace, no allocation, no synchronisation. */
+ * to rpg_conv2d_bn_act_nhwc_bf16 called twice.  Maps up to 62 pixels wide as they are, up to 120 (round 6: the 64 x 86 maps of the
+ * 256 x 341 evaluation shape, dataset_7Scenes_multi.py:341,434) as two column strips per image whose two columns next to the cut are
+ * recomputed; RPG_ERR_BAD_ARG for shapes it does not take (w < 4, w > 120, a strip's activations beyond 2^31 bytes: the caller then
+ * uses two convolution calls).  No workspace, no allocation, no synchronisation. */
 int rpg_basicblock64_bf16(const void* x, const void* w1_ohwi, const float* scale1, const float* shift1, const void* w2_ohwi,
                           const float* scale2, const float* shift2, void* y, int n, int h, int w, void* stream);
 

@@ -470,13 +470,18 @@ def test_bf16_gnn_forward_vs_fp32(dev):
     assert torch.equal(a2, a32) and torch.equal(r2, r32)
 
 
-@pytest.mark.parametrize("shape", [(3, 56, 56), (7, 14, 56), (5, 24, 40), (1, 56, 56), (40, 56, 56)])
+@pytest.mark.parametrize("shape", [(3, 56, 56), (7, 14, 56), (5, 24, 40), (1, 56, 56), (40, 56, 56),
+                                   (2, 64, 86), (3, 43, 64), (9, 64, 86), (2, 20, 85), (1, 30, 120), (3, 30, 63)])
 def test_fused_basicblock64_equals_two_convolutions(dev, shape):
     """Round 5: conv1 + BN + ReLU + conv2 + BN + identity + ReLU of a 64-channel BasicBlock as ONE kernel
     with the intermediate in LDS (csrc/block_bf16.inc; torchvision BasicBlock reached from modules/posenet.py:1037).  The
     intermediate is rounded to bf16 exactly where the two-launch path stores it, so the outputs must be BIT-IDENTICAL to two
     rpg_conv2d_bn_act_nhwc_bf16 calls: tiles straddling image boundaries (14-row images), a 40-wide map (48-slot patch rows),
-    ragged last tiles, a single image, and 40 images (245 tiles)."""
+    ragged last tiles, a single image, and 40 images (245 tiles).
+    Round 6: maps wider than 63 pixels run as two column strips per image (virtual images of ceil(W / 2) + 2
+    columns, the two columns next to the cut recomputed and not stored): the 64 x 86 layer-1 maps of the 256 x 341 evaluation
+    shape (datasets/dataset_7Scenes_multi.py:341,434), 43 x 64, odd widths (85: the strips' shares differ by one column), the
+    widest map taken (120), and 63 (one column too wide for a single strip's 64-slot patch rows: two strips)."""
     from relpose_gnn_amd import ops
     n, h, w = shape
     g = torch.Generator().manual_seed(1000 + n * h + w)
@@ -488,10 +493,25 @@ def test_fused_basicblock64_equals_two_convolutions(dev, shape):
     # the two-launch reference on the PATCH kernel (RPG_TUNE_BF16_PATCH = 2: wherever eligible; the dispatcher picks it by itself
     # from 21 images of 56x56 up): the fused kernel walks K in the patch kernel's order (32-channel chunk major, tap minor);
     # below that size the dispatcher's im2col kernel sums tap major and differs in the last bf16 bit of ~0.04 % of the outputs
+    def two_launches(xx):
+        t = ops.conv2d_bn_act_nhwc_bf16(xx, w1, s1, b1, None, stride=1, pad=1, relu=True)
+        return ops.conv2d_bn_act_nhwc_bf16(t, w2, s2, b2, xx, stride=1, pad=1, relu=True)
+
     ops.set_tuning(ops.TUNE_BF16_PATCH, 2)
     try:
-        t = ops.conv2d_bn_act_nhwc_bf16(x, w1, s1, b1, None, stride=1, pad=1, relu=True)
-        want = ops.conv2d_bn_act_nhwc_bf16(t, w2, s2, b2, x, stride=1, pad=1, relu=True)
+        if w <= 62:
+            want = two_launches(x)
+        else:
+            # Two-strip launches: the bit-exact reference is the patch-kernel pair on each strip's VIEW of the image (the patch
+            # kernel does not take 86-wide maps -- more than 64 patch pieces --, and the im2col kernel the dispatcher uses there sums
+            # tap major: last-bit differences in ~0.04 % of the outputs).  View = ceil(w / 2) + 2 columns ending at the image edge;
+            # the strip's own share of the columns is compared, the two columns next to the cut are recomputed by both strips.
+            ws = (w + 1) // 2
+            wv = ws + 2
+            y0 = two_launches(x[:, :, :wv, :].contiguous())
+            y1 = two_launches(x[:, :, w - wv:, :].contiguous())
+            want = torch.cat([y0[:, :, :ws, :], y1[:, :, ws - (w - wv):, :]], dim=2)
+            whole = two_launches(x)                       # what the encoder runs with the fusion off: equal up to summation order
     finally:
         ops.set_tuning(ops.TUNE_BF16_PATCH, 1)
     got = ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2)
@@ -499,6 +519,9 @@ def test_fused_basicblock64_equals_two_convolutions(dev, shape):
     assert got.shape == want.shape and bool(torch.isfinite(got.float()).all())
     bad = (got != want).nonzero()
     assert bad.numel() == 0, (shape, int(bad.shape[0]), bad[:5].tolist(), float((got.float() - want.float()).abs().max()))
+    if w > 62:
+        off = got != whole
+        assert float(off.float().mean()) < 2e-3 and rel_err(got.float(), whole.float()) < 1e-2
     # and against an fp32 reference of the block on the same bf16 operands (bf16 bar of this file's convolution tests)
     xf = x.float().permute(0, 3, 1, 2).cpu()
     tf = torch.relu(torch.nn.functional.conv2d(xf, w1.float().permute(0, 3, 1, 2).cpu(), padding=1) * s1.cpu().view(1, -1, 1, 1) + b1.cpu().view(1, -1, 1, 1))
@@ -508,10 +531,10 @@ def test_fused_basicblock64_equals_two_convolutions(dev, shape):
 
 
 def test_fused_basicblock64_refuses_shapes_it_does_not_take(dev):
-    """Maps wider than 63 pixels (the 256x341 evaluation shape: 64x86 at layer 1) are outside the fused kernel's patch budget: the
-    entry point says so (RPG_ERR_BAD_ARG) and the composite forward falls back to two launches (same results either way)."""
+    """Maps wider than 120 pixels (two strips of 60 + 2 columns: the widest whose patch rows fit 64 slots) are outside the fused kernel's patch budget: the entry point says so
+    (RPG_ERR_BAD_ARG) and the composite forward falls back to two launches (same results either way)."""
     from relpose_gnn_amd import _lib, ops
-    x = torch.zeros((1, 64, 86, 64), dtype=torch.bfloat16, device=dev)
+    x = torch.zeros((1, 64, 123, 64), dtype=torch.bfloat16, device=dev)
     wz = torch.zeros((64, 3, 3, 64), dtype=torch.bfloat16, device=dev)
     v = torch.ones(64, device=dev)
     with pytest.raises((ValueError, _lib.RpgError)):

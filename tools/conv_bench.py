@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="rpg_set_tuning(KEY, VALUE)")
     ap.add_argument("--block64", action="store_true", help="bf16: the fused 64-channel BasicBlock kernel (rpg_basicblock64_bf16) against its "
                     "two convolution launches on the same operands, interleaved (layer 1 of ResNet34: 56x56x64)")
+    ap.add_argument("--block64-map", default="56x56", help="with --block64: the layer-1 map (56x56 at 224x224 images, 64x86 at 256x341)")
     ap.add_argument("--dma-sweep", default="", help="bf16 only: comma-separated configuration indices of the LDS-DMA kernel; every shape "
                     "is timed with the default dispatch and with each of them (RPG_TUNE_BF16_DMA = 10 + i) interleaved in one process")
     args = ap.parse_args()
@@ -100,7 +101,8 @@ def main():
         ops.set_tuning(ops.TUNE_BF16_WS64, int(os.environ["RPG_WS64"]))
     print(f"# bk={args.bk} epi={args.epi} tile={args.tile} streamk={args.sk}", flush=True)
     if args.block64:
-        n, h, w = args.nimg, 56, 56
+        h, w = (int(v) for v in args.block64_map.split("x"))
+        n = args.nimg
         g = torch.Generator(device=dev).manual_seed(5)
         x = torch.randn((n, h, w, 64), generator=g, device=dev).bfloat16()
         w1 = (torch.randn((64, 3, 3, 64), generator=g, device=dev) * (2.0 / 576) ** 0.5).bfloat16()
@@ -116,7 +118,7 @@ def main():
         for rep in range(3):
             m2, _ = timeit(two, args.reps)
             m1, _ = timeit(lambda: ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2), args.reps)
-            print(f"block64 images={n}  two launches {m2*1e3:7.1f} us ({fl/m2/1e9:6.1f} TF)   fused {m1*1e3:7.1f} us ({fl/m1/1e9:6.1f} TF)   "
+            print(f"block64 images={n} map {h}x{w}  two launches {m2*1e3:7.1f} us ({fl/m2/1e9:6.1f} TF)   fused {m1*1e3:7.1f} us ({fl/m1/1e9:6.1f} TF)   "
                   f"ratio {m1/m2:.3f}   bit-identical {same}", flush=True)
         return
     for name, n, h, w, cin, cout, k, s, p, res in SHAPES:
