@@ -659,7 +659,7 @@ def main():
             # PMC counters cannot be read from inside the process: they come from a COMMITTED rocprofv3 --pmc profile of
             # this command, used only if it was taken at this batch size, and labelled with the kernel sources it saw
             from relpose_gnn_amd.build import WINOGRAD_SOURCES, source_digest
-            tpath = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_pmc_wino43.json") for r in (5, 4, 3, 2)) if os.path.exists(p)), None)
+            tpath = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_pmc_wino43.json") for r in (6, 5, 4, 3, 2)) if os.path.exists(p)), None)
             if tpath is not None:
                 with open(tpath) as f:
                     tj = json.load(f)

@@ -25,7 +25,7 @@ timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_bf16_fetch" -o p -- python3 $PB > "$OUT/pmc_bf16_fetch.log" 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_bf16_write" -o p -- python3 $PB > "$OUT/pmc_bf16_write.log" 2>&1
 cd "$R"
-for k in block64_bf16_fused conv3x3_bf16_patch conv_bf16_dma stem_pool_bf16; do
+for k in block64_bf16_fused conv3x3_bf16_patch conv_bf16_dma stem_strip_bf16; do
   python3 tools/pmc_summary.py "$OUT" $k >> "$OUT/pmc_bf16_summary.txt" 2>&1
 done
 f=$(ls "$OUT"/trace_bf16_1stream/*kernel_stats.csv 2>/dev/null | head -1)
