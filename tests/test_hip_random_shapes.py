@@ -193,3 +193,62 @@ def test_random_conv_bf16(dev, case):
                                     scale.to(dev), shift.to(dev), None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev),
                                     stride=stride, pad=pad, relu=relu)
     assert rel_err(y.float().cpu().permute(0, 3, 1, 2), ref) < 1e-2, (kh, stride, pad, cin, cout, n, h, w)
+
+
+@pytest.mark.parametrize("case", range(20))
+def test_random_stem_bf16_strips(dev, case):
+    """Round 6: the strip-march stem (csrc/stem_bf16.hip; torchvision conv1 / bn1 / relu / maxpool reached from posenet.py:1037) on
+    random image counts and sizes -- ragged strips (pooled widths that are no multiple of 15), ragged bands, odd convolution heights
+    and widths, images narrower than one strip, odd image sizes with bf16 input (rows and images that start 2 bytes past a dword)
+    -- in every variant of the kernel, fp32 and host-rounded bf16 input (bit-identical), against conv2d + BN + ReLU + max_pool2d
+    on the same bf16-rounded operands."""
+    from relpose_gnn_amd import ops
+    from relpose_gnn_amd.params import pack_stem_bf16
+    rng = random.Random(4000 + case)
+    n, h, w = rng.randint(1, 9), rng.randint(1, 150), rng.randint(1, 260)
+    variant = rng.choice([1, 33, 5, 17]) + (rng.choice([0, 3, 7, 11]) << 8)
+    x = _rand(n, 3, h, w, seed=case)
+    wt = _rand(64, 3, 7, 7, seed=case + 1, scale=(2.0 / 147) ** 0.5)
+    g = torch.Generator().manual_seed(case + 2)
+    scale = (torch.rand(64, generator=g) + 0.5) * torch.where(torch.rand(64, generator=g) < 0.2, -1.0, 1.0)
+    shift = _rand(64, seed=case + 3, scale=0.3)
+    conv = F.conv2d(x.bfloat16().float(), wt.bfloat16().float(), None, stride=2, padding=3)
+    ref = F.max_pool2d(F.relu(conv * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)), 3, 2, 1).bfloat16().float()
+    ops.set_tuning(ops.TUNE_FUSED_STEM, variant)
+    try:
+        wp = pack_stem_bf16(wt).to(dev)
+        y = ops.stem_conv_bn_relu_maxpool_bf16(x.to(dev), wp, scale.to(dev), shift.to(dev))
+        y16 = ops.stem_conv_bn_relu_maxpool_bf16(x.bfloat16().to(dev), wp, scale.to(dev), shift.to(dev))
+    finally:
+        ops.set_tuning(ops.TUNE_FUSED_STEM, 1)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape and torch.equal(y, y16), (n, h, w, variant)
+    assert rel_err(got, ref) < 1e-2, (n, h, w, variant)
+    assert float((got - ref).abs().mean() / ref.abs().mean().clamp(min=1e-30)) < 3e-4, (n, h, w, variant)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_random_fused_basicblock64(dev, case):
+    """Round 6: the fused 64-channel BasicBlock (csrc/block_bf16.inc) on random maps 4..120 pixels wide -- one strip up to 62, two
+    column strips beyond --, random heights and image counts (tiles straddling images and strips), against the block in fp32 on
+    the same bf16 operands with the intermediate rounded to bf16 (the bf16 bar of the convolution tests); shapes the kernel does not
+    take must say so (ValueError), never give wrong numbers."""
+    from relpose_gnn_amd import ops
+    rng = random.Random(5000 + case)
+    n, h, w = rng.randint(1, 6), rng.randint(1, 70), rng.randint(4, 120)
+    g = torch.Generator().manual_seed(case)
+    x = torch.randn((n, h, w, 64), generator=g).bfloat16()
+    w1 = (torch.randn((64, 3, 3, 64), generator=g) * (2.0 / 576) ** 0.5).bfloat16()
+    w2 = (torch.randn((64, 3, 3, 64), generator=g) * (2.0 / 576) ** 0.5).bfloat16()
+    s1, b1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    s2, b2 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    try:
+        got = ops.basicblock64_bf16(x.to(dev), w1.to(dev), s1.to(dev), b1.to(dev), w2.to(dev), s2.to(dev), b2.to(dev))
+    except ValueError:
+        pytest.skip(f"shape {(n, h, w)} not taken by the fused kernel (LDS budget): the encoder uses two launches")
+    xf = x.float().permute(0, 3, 1, 2)
+    tf = torch.relu(F.conv2d(xf, w1.float().permute(0, 3, 1, 2), padding=1) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1)).bfloat16().float()
+    yf = torch.relu(F.conv2d(tf, w2.float().permute(0, 3, 1, 2), padding=1) * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1) + xf)
+    gotf = got.float().cpu().permute(0, 3, 1, 2)
+    assert rel_err(gotf, yf) < 1e-2, (n, h, w)
+    assert float((gotf - yf).abs().mean() / yf.abs().mean().clamp(min=1e-30)) < 3e-3, (n, h, w)

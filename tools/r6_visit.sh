@@ -1,4 +1,3 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6i; mkdir -p $OUT
-bash tools/gpu_check.sh r6i > $OUT/gpu_check.log 2>&1; tail -8 $OUT/gpu_check.log | cut -c1-600
-bash tools/collect_profiles.sh r6 > $OUT/collect.log 2>&1; tail -5 $OUT/collect.log
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6j; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_hip_random_shapes.py -q -m gpu -k "stem or basicblock" > $OUT/pytest.log 2>&1; echo "rc=$?" >> $OUT/pytest.log; tail -15 $OUT/pytest.log
