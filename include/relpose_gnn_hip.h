@@ -401,6 +401,8 @@ int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
 #define RPG_TUNE_FIXUP_PRIO 30       /* experiment of round 6, OFF by default: 1 = the fix-up launches of split tiles (Winograd tail, stream-K) run on a
                                      high-priority companion of the launch stream (event hand-off there and back), so that under two concurrent
                                      streams they are dispatched ahead of the other stream's queued convolution workgroups */
+#define RPG_TUNE_BF16_PAIR 31        /* bf16 encoder: 1 (default) = the 3x3 / stride-2 convolution and the 1x1 / stride-2 shortcut of a down-sampling BasicBlock
+                                     run as ONE launch of the LDS-DMA kernel (their tiles side by side in the grid; same arithmetic) | 0 = two launches */
 int rpg_set_tuning(int key, int value);
 
 #ifdef __cplusplus

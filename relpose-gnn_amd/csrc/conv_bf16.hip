@@ -558,8 +558,8 @@ __device__ __forceinline__ void dma_piece16(__amdgpu_buffer_rsrc_t rsrc, unsigne
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int ST>
-__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a, const __bf16* __restrict__ Wt, int M, int N, int K,
-                                                                       EpiB ep, int tiles_n) {
+__device__ __forceinline__ void conv_bf16_dma_body(const ConvArgsB& a, const __bf16* __restrict__ Wt, int M, int N, int K, const EpiB& ep,
+                                                   int tiles_n, int bid, int nwg) {
     constexpr int NW = WM * WN;
     constexpr int CH = BK / 8, RPG = 64 / CH;                  // 16-byte chunks per row; rows per 1-KB piece
     constexpr int NA = BM / RPG, NB = BN / RPG;                // pieces per image
@@ -572,7 +572,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
     static_assert((ST - 2) * NJ < 64, "vmcnt is 6 bits");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
-    const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3, q = nwg >> 3, r = nwg & 7;
     const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     const int m0 = (tile / tiles_n) * BM;
@@ -729,6 +728,31 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     bf16_tile_epilogue_any<FM, FN, ST * IMG_B, NW>(acc, lds_raw, ep, m0, n0, M, N, wm, wn, lane, wave);
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int ST>
+__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_kernel(ConvArgsB a, const __bf16* __restrict__ Wt, int M, int N, int K,
+                                                                       EpiB ep, int tiles_n) {
+    conv_bf16_dma_body<BM, BN, WM, WN, BK, ST>(a, Wt, M, N, K, ep, tiles_n, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Round 6: TWO convolutions in one launch -- the 3x3 / stride-2 convolution and the 1x1 / stride-2 shortcut of
+// a down-sampling BasicBlock (torchvision BasicBlock.downsample, reached from modules/posenet.py:1037), which read the same input.
+// Workgroups [0, t1) are the tiles of the first, the rest those of the second (arguments selected by the block index: scalar
+// selects); same tile template, same arithmetic per output as the two launches.  What it buys: one launch gap less per
+// down-sampling block and the shortcut's tiles filling the partly empty last round of the 3x3's (392 / 196 tiles on 256 CUs).
+struct DmaOne {
+    ConvArgsB a;
+    const __bf16* Wt;
+    int M, N, K, tiles_n;
+    EpiB ep;
+};
+template <int BM, int BN, int WM, int WN, int BK, int ST>
+__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_dma_pair_kernel(DmaOne c1, DmaOne c2, int t1) {
+    const bool first = (int)blockIdx.x < t1;
+    const DmaOne& c = first ? c1 : c2;
+    conv_bf16_dma_body<BM, BN, WM, WN, BK, ST>(c.a, c.Wt, c.M, c.N, c.K, c.ep, c.tiles_n, first ? (int)blockIdx.x : (int)blockIdx.x - t1,
+                                               first ? t1 : (int)gridDim.x - t1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1185,6 +1209,24 @@ void launch_dma(const ConvArgsB& a, const __bf16* w, int M, int N, int K, const 
     hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(64 * WM * WN), lds, s, a, w, M, N, K, ep, tn);
 }
 
+template <int BM, int BN, int WM, int WN, int BK, int ST>
+void launch_dma_pair(const DmaOne& c1in, const DmaOne& c2in, hipStream_t s) {
+    constexpr int lds = ST * (BM + BN) * BK * 2;
+    auto kern = conv_bf16_dma_pair_kernel<BM, BN, WM, WN, BK, ST>;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    static bool once[64] = {};
+    if (!once[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        once[dev] = true;
+    }
+    DmaOne c1 = c1in, c2 = c2in;
+    c1.tiles_n = (c1.N + BN - 1) / BN; c2.tiles_n = (c2.N + BN - 1) / BN;
+    const int t1 = ((c1.M + BM - 1) / BM) * c1.tiles_n, t2 = ((c2.M + BM - 1) / BM) * c2.tiles_n;
+    hipLaunchKernelGGL(kern, dim3(t1 + t2), dim3(64 * WM * WN), lds, s, c1, c2, t1);
+}
+int g_bf16_pair = 1;     // RPG_TUNE_BF16_PAIR: the strided 3x3 + 1x1 shortcut pair of a down-sampling block in one launch
+
 int g_bf16_stages = 4;   // weight stages of the patch kernel (experiments: 3 = never the prefetching form); RPG_TUNE_BF16_PATCH + 10
 // RPG_TUNE_BF16_PERSIST: the persistent form of the patch kernel (cross-tile prefetch) on the 64-channel layer.  OFF by default: the kernel
 // itself is 10 % (in the model) to 15 % (stand-alone) faster, but 256 resident workgroups hold every CU for the whole launch, and the
@@ -1483,6 +1525,39 @@ int launch_linear_bf16_ex(const void* a, int lda, const void* w, const float* bi
     return RPG_OK;
 }
 
+void bf16_set_pair(int v) { g_bf16_pair = v; }
+
+// conv A (kh x kw / stride / pad) and conv B (1 x 1 / same stride, pad 0) of the same input x [n][h][w][cin] -> ya, yb (both
+// [n][ho][wo][cout], bf16, BN folded, ReLU on A only per `relu_a`); false: not eligible (the caller launches them one by one)
+bool launch_conv_pair_bf16(const void* x, const void* wa, const float* sa, const float* ha, void* ya, const void* wb_, const float* sb,
+                           const float* hb, void* yb, int n, int h, int wd, int cin, int cout, int k, int stride, int pad, hipStream_t s) {
+    if (!g_bf16_pair || g_bf16_dma != 1 || !x || !wa || !wb_ || !ya || !yb || n <= 0 || (cin & 31) || (cout & 3)) return false;
+    const int ho = conv_out(h, k, stride, pad), wo = conv_out(wd, k, stride, pad);
+    if (ho <= 0 || wo <= 0 || ho != conv_out(h, 1, stride, 0) || wo != conv_out(wd, 1, stride, 0)) return false;
+    const long M = (long)n * ho * wo, Ka = (long)k * k * cin, Kb = cin;
+    if (M < 8192 || M >= (1L << 31) || Ka >= (1 << 24)) return false;
+    const long span1k = 1024 / ((long)ho * wo) + 2;
+    if (span1k * h * wd * cin * 2 >= (1L << 31) || (long)cout * Ka * 2 >= (1L << 31)) return false;
+    if (!aligned16(x) || !aligned16(wa) || !aligned16(wb_) || !aligned16(ya) || !aligned16(yb)) return false;
+    DmaOne c1{}, c2{};
+    c1.a = ConvArgsB{reinterpret_cast<const __bf16*>(x), h, wd, cin, k, k, stride, pad, ho, wo};
+    c2.a = ConvArgsB{reinterpret_cast<const __bf16*>(x), h, wd, cin, 1, 1, stride, 0, ho, wo};
+    c1.Wt = reinterpret_cast<const __bf16*>(wa); c2.Wt = reinterpret_cast<const __bf16*>(wb_);
+    c1.M = c2.M = (int)M; c1.N = c2.N = cout; c1.K = (int)Ka; c2.K = (int)Kb;
+    c1.ep = EpiB{sa, ha, nullptr, ya, cout, 1, 0};
+    c2.ep = EpiB{sb, hb, nullptr, yb, cout, 0, 0};
+    const bool lean = g_bf16_lean_epi && 1024L * cout * 2 < (1L << 31);
+    c1.ep.lean = lean; c2.ep.lean = lean;
+    const int slot = timing_begin(RPG_TIMER_CONV, s);
+    // the tile template of launch_conv_bf16's choice for the 3x3 (configuration 7 up to 128 channels, 0 above where 256 x 256 tiles
+    // fill three quarters of the CUs); the shortcut takes the same (its own choice by shape is the same in ResNet34)
+    const long t256 = ((M + 255) / 256) * ((cout + 255) / 256);
+    if (cout <= 128 || 4 * t256 < 3L * num_cus() || cin % 64) launch_dma_pair<256, 128, 4, 2, 32, 3>(c1, c2, s);
+    else launch_dma_pair<256, 256, 2, 4, 64, 2>(c1, c2, s);
+    timing_end(slot, 2.0 * (double)M * cout * (double)(Ka + Kb), s);
+    return hipGetLastError() == hipSuccess;
+}
+
 int launch_conv_bf16(const void* x, const void* w, const float* scale, const float* shift, const void* residual, void* y,
                      int n, int h, int wd, int cin, int cout, int kh, int kw, int stride, int pad, int relu, int out_f32,
                      hipStream_t s) {
@@ -1759,11 +1834,18 @@ static int resnet_forward_bf16_impl(const void* const* tensors, int n_tensors, c
                 }
                 rpg::timing_end(slot, 0.0, s);
             }
-            if ((rc = rpg::launch_conv_bf16(X, tensors[ti], (const float*)tensors[ti + 1], (const float*)tensors[ti + 2],
-                                            nullptr, T, n, hh, ww, cin, c, 3, 3, stride, 1, 1, 0, s)) != RPG_OK)
-                return rc;
             const void* identity = X;
-            if (ds) {
+            bool paired = false;
+            if (ds && stride == 2)
+                paired = rpg::launch_conv_pair_bf16(X, tensors[ti], (const float*)tensors[ti + 1], (const float*)tensors[ti + 2], T, tensors[ti + 6],
+                                                    (const float*)tensors[ti + 7], (const float*)tensors[ti + 8], D, n, hh, ww, cin, c, 3, stride, 1, s);
+            if (paired) {
+                identity = D;
+            } else if ((rc = rpg::launch_conv_bf16(X, tensors[ti], (const float*)tensors[ti + 1], (const float*)tensors[ti + 2],
+                                                   nullptr, T, n, hh, ww, cin, c, 3, 3, stride, 1, 1, 0, s)) != RPG_OK) {
+                return rc;
+            }
+            if (ds && !paired) {
                 if ((rc = rpg::launch_conv_bf16(X, tensors[ti + 6], (const float*)tensors[ti + 7], (const float*)tensors[ti + 8],
                                                 nullptr, D, n, hh, ww, cin, c, 1, 1, stride, 0, 0, 0, s)) != RPG_OK)
                     return rc;

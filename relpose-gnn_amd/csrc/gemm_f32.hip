@@ -770,6 +770,7 @@ extern "C" int rpg_release_scratch(void) {
 extern "C" int rpg_set_tuning(int key, int value) {
     switch (key) {
         case RPG_TUNE_FIXUP_PRIO: g_fixup_prio = value != 0; return RPG_OK;
+        case RPG_TUNE_BF16_PAIR: rpg::bf16_set_pair(value != 0); return RPG_OK;
         case RPG_TUNE_TILE: g_force_tile = value; return RPG_OK;
         case RPG_TUNE_BK: if (value != 0 && value != 16 && value != 32) return RPG_ERR_BAD_ARG; g_bk = value; return RPG_OK;
         case RPG_TUNE_EPILOGUE: g_epi_lds = value != 0; return RPG_OK;

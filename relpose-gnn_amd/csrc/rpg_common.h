@@ -105,6 +105,7 @@ void bf16_set_lean_epi(int on);
 void bf16_set_persist(int v);
 void bf16_set_fuse_block(int v);
 void bf16_set_tail(int v);
+void bf16_set_pair(int v);
 void bf16_set_linear_dma(int v);
 int bf16_set_ws64(int v);      // RPG_OK, or RPG_ERR_BAD_ARG for v != 0 in a build without the probe kernel (tools/probes/conv3x3_bf16_ws64.inc)
 bool stem_pool_bf16_supported(int n, int h, int w, int cout);      // incl. the ranges the kernel's magic divisions are exact for

@@ -397,7 +397,7 @@ def release_scratch() -> None:
     L.check(L.lib().rpg_release_scratch(), "release_scratch")
 
 
-TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST, TUNE_FUSED_STEM, TUNE_WAVES8, TUNE_WINO_SHORT, TUNE_GNN_FUSE_AGG, TUNE_WINO_PERSIST, TUNE_BF16_TILE, TUNE_BF16_DMA, TUNE_BF16_PATCH, TUNE_BF16_WS64, TUNE_SK_MIN_ITS, TUNE_INKERNEL_FIXUP, TUNE_BF16_CHUNK, TUNE_WINO2D, TUNE_BF16_LEAN_EPI, TUNE_BF16_LINEAR_DMA, TUNE_BF16_PERSIST, TUNE_FOLD_K, TUNE_BF16_FUSE_BLOCK, TUNE_BF16_TAIL, TUNE_LIN112, TUNE_FIXUP_PRIO = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30
+TUNE_TILE, TUNE_BK, TUNE_EPILOGUE, TUNE_STREAMK, TUNE_WINOGRAD, TUNE_GNN_SPLIT, TUNE_BF16_BK, TUNE_FAST_LOADER, TUNE_WINO_SPLIT, TUNE_BF16_FAST, TUNE_FUSED_STEM, TUNE_WAVES8, TUNE_WINO_SHORT, TUNE_GNN_FUSE_AGG, TUNE_WINO_PERSIST, TUNE_BF16_TILE, TUNE_BF16_DMA, TUNE_BF16_PATCH, TUNE_BF16_WS64, TUNE_SK_MIN_ITS, TUNE_INKERNEL_FIXUP, TUNE_BF16_CHUNK, TUNE_WINO2D, TUNE_BF16_LEAN_EPI, TUNE_BF16_LINEAR_DMA, TUNE_BF16_PERSIST, TUNE_FOLD_K, TUNE_BF16_FUSE_BLOCK, TUNE_BF16_TAIL, TUNE_LIN112, TUNE_FIXUP_PRIO, TUNE_BF16_PAIR = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31
 
 
 def set_tuning(key: int, value: int) -> None:

@@ -568,6 +568,36 @@ def test_bf16_encoder_with_and_without_block_fusion_is_bit_identical(dev):
     assert bool(torch.isfinite(outs[0][0]).all()) and float(outs[0][0].abs().max()) > 0
 
 
+def test_bf16_encoder_paired_downsample_launch_is_bit_identical(dev):
+    """Round 6: the 3x3 / stride-2 convolution and the 1x1 / stride-2 shortcut of a down-sampling BasicBlock
+    (torchvision BasicBlock.downsample, reached from modules/posenet.py:1037) as ONE launch of the LDS-DMA kernel
+    (RPG_TUNE_BF16_PAIR, default on) / as two launches: same tiles, same arithmetic -- the poses of the bf16 model are equal bit for
+    bit, at 224x224 (48 images: layers 2-4 all pair) and at an odd-sized 136x200 input."""
+    import relpose_gnn_amd.synth as S
+    from relpose_gnn_amd import ops
+    from relpose_gnn_amd.graph import fc_batch
+    from relpose_gnn_amd.posenet import PoseNetX_R2
+    from relpose_gnn_amd.resnet import resnet34
+    D = 2048
+    for (hh, ww, nimg) in ((224, 224, 48), (136, 200, 64)):
+        m = PoseNetX_R2(resnet34(), droprate=0.0, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D,
+                        input_img_height=hh, use_gnn=True, knn=-1, use_AP=True, gnn_recursion=2)
+        m.load_state_dict(S.synth_state_dict(S.posenet_r2_param_shapes(D, D, D), seed=1))
+        m = m.to(dev).eval()
+        m.encoder_dtype = "bf16"
+        d = fc_batch(S.synth_images(nimg, hh, ww, seed=19), 8).to(dev)
+        outs = []
+        try:
+            for pair in (1, 0):
+                ops.set_tuning(ops.TUNE_BF16_PAIR, pair)
+                a, r, _ = m(d)
+                outs.append((a.clone(), r.clone()))
+        finally:
+            ops.set_tuning(ops.TUNE_BF16_PAIR, 1)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (hh, ww)
+        assert bool(torch.isfinite(outs[0][0]).all()) and float(outs[0][0].abs().max()) > 0
+
+
 def test_conv_bf16_lean_epilogue_without_relu_keeps_nan(dev):
     """the lean epilogue clamped with max(y, relu ? 0 : -inf), which turns a NaN accumulator of a NON-ReLU convolution
     (the 1x1 downsample) into -inf where the general epilogue and the reference propagate it.  Now a select: relu = False on
