@@ -393,7 +393,8 @@ int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
                                      go to a second launch of the patch kernel with smaller tiles instead of a mostly empty round of full-size ones
                                      (49 * 2^k pixels: 3.06 / 1.53 rounds at 512 images); same arithmetic per output, bit-identical.  Bit 0 (default
                                      on): 512 x 128 -> 256 x 128 tiles (layer 2: -4..5 %); bit 1 (off): 256 x 256 -> 160 x 256 (layer 3: measured
-                                     no gain); 0 = always one launch */
+                                     no gain); bit 2 (off, round 6): layer 2's tail on 128 x 128 tiles instead of 256 x 128 (measured: no gain,
+                                     0.350 vs 0.351); 0 = always one launch */
 #define RPG_TUNE_LIN112 29           /* fp32 Linears with a plain A operand, M % 112 == 0, N % 64 == 0, K % 32 == 0 and at least one 112 x 64 tile per CU (the
                                      GNN's edge GEMMs: M = 56 edges x graphs = 7 * 2^k rows): bit 0 = the exact-fit kernel on v_mfma_f32_16x16x4_f32
                                      (no stream-K split, no fix-up launch), bit 1 = its eight-wave form (the two k halves of a step on two wave

@@ -1446,7 +1446,7 @@ void bf16_set_fused_stem(int on) { g_bf16_fused_stem = on; }
 void bf16_set_lean_epi(int on) { g_bf16_lean_epi = on; }
 void bf16_set_persist(int v) { g_bf16_persist = v; }
 void bf16_set_fuse_block(int v) { g_bf16_fuse_block = v; }
-void bf16_set_tail(int v) { g_bf16_tail = v & 3; }
+void bf16_set_tail(int v) { g_bf16_tail = v & 7; }
 void bf16_set_linear_dma(int v) { g_bf16_linear_dma = v; }
 void bf16_set_chunk(int images, int min_mb) { g_bf16_chunk = images; g_bf16_chunk_mb = min_mb; }
 #ifdef RPG_PROBE_WS64
@@ -1638,10 +1638,12 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
         } else if (cout > 64 && big) {
             // (the persistent form of this tile was built and measured slower -- 141 -> 179 us: at 256 VGPRs the next tile's piece
             // addresses, computed in front of the last chunk with the accumulators live, spill 65-113 registers)
-            const int m_main = (g_bf16_tail & 1) ? tail_split(512, 256) : 0;
+            // (bit 2, round-6 experiment: the tail on 128 x 128 tiles -- twice the workgroups, half the rows each)
+            const int m_main = (g_bf16_tail & 1) ? tail_split(512, (g_bf16_tail & 4) ? 128 : 256) : 0;
             done = (g_bf16_stages != 3 && launch_patch<512, 128, 4, 2, 4>(a, wp, n, (int)M, cout, ep, s, 0, m_main)) ||
                    launch_patch<512, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s, 0, m_main);
-            if (done && m_main && !launch_patch<256, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s, m_main, 0))
+            if (done && m_main && (g_bf16_tail & 4) && launch_patch<128, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s, m_main, 0)) {
+            } else if (done && m_main && !launch_patch<256, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s, m_main, 0))
                 done = launch_patch<512, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s, m_main, 0);
         } else if (g_bf16_patch >= 2 || big) {
             // 64 output channels (layer 1).  Round 3 measured 232-245 us at 512 images against 205-222 us for the im2col DMA kernel
