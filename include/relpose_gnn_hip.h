@@ -332,7 +332,8 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
                                      strip-march kernel (none of these bits: the default, bit 3): bit 3 = both 32-channel halves in one wave, weights in
                                      LDS, two waves per SIMD; bit 5 = one half per wave, weights in LDS, three waves per SIMD; bit 2 = one half per wave,
                                      weights in registers, two waves; bit 4 = one half per wave, four waves per SIMD; value >> 8 = pooled rows per band
-                                     (0, the default: by the launch's size) */
+                                     (0, the default: by the launch's size).  fp32 stem: bit 7 = the strip-march kernel (round 6; opt-in: 6-12 % faster
+                                     than the tile kernel, every fp32 bar holds, but it re-rolls the rounding noise of the noise-floor ratio test) */
 #define RPG_TUNE_WINO_SPLIT 8     /* 1: split-K tail + fix-up for the 8-wave Winograd kernel (default) | 0: whole tiles only | n >= 2: as 1, and a part of a
                                      tile gets at least n K steps in the one-workgroup-per-tile form (default 3: one 8-node graph 1.50 ms per forward, 1.63 with 4) */
 #define RPG_TUNE_FAST_LOADER 7    /* 1: buffer-load loaders + interleaved main loop where eligible (default) | 0: general loaders */

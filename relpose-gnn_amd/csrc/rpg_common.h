@@ -90,6 +90,7 @@ bool wino2d_takes(int n, int h, int w, int cin, int cout);
 int launch_conv_wino2d(const float* x, const float* u2, const float* scale, const float* shift, const float* residual, float* y,
                        int n, int h, int w, int cin, int cout, int relu, hipStream_t s);
 void stem_pool_set(int on);
+void stem_pool_set_strip(int on, int band_rows);      // stem.hip: fp32 strip-march kernel (round 6) | tile kernel (rounds 2-5)
 void wino_split_set(int on);
 void wino_short_set(int cin);
 void wino_persist_set(int on);

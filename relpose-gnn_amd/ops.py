@@ -182,8 +182,8 @@ def stem_conv_bn_relu_maxpool(x_nchw: torch.Tensor, wpack: torch.Tensor, shift: 
     params.pack_stem_pairs (BatchNorm scale folded in), shift [64]."""
     x, wpack, shift = _req(x_nchw, "x_nchw"), _req(wpack, "wpack"), _req(shift, "shift")
     n, c, h, w = x.shape
-    if c != 3 or tuple(wpack.shape) != (74, 2, 64) or shift.numel() != 64:
-        raise ValueError("expected x [N,3,H,W], wpack [74,2,64], shift [64]")
+    if c != 3 or wpack.numel() != (74 + 75) * 2 * 64 or shift.numel() != 64:
+        raise ValueError("expected x [N,3,H,W], wpack from params.pack_stem_pairs (19,072 floats), shift [64]")
     hc, wc = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     y = torch.empty((n, (hc - 1) // 2 + 1, (wc - 1) // 2 + 1, 64), dtype=torch.float32, device=x.device)
     L.check(L.lib().rpg_stem_conv7x7s2_bn_relu_maxpool_f32(_p(x), _p(wpack), _p(shift), _p(y), n, h, w, _stream()),

@@ -64,8 +64,8 @@ def stem_pair_table() -> Tuple[List[Tuple[int, int, int]], List[Optional[Tuple[i
 
 
 def pack_stem_pairs(w_oihw: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
-    """conv1.weight [64][3][7][7] and the folded BatchNorm scale [64] -> wpack [74][2][64] of
-    rpg_stem_conv7x7s2_bn_relu_maxpool_f32: element [kp][nf][l] = scale[ch] * W[ch][tap], ch = 32 nf + (l & 31), tap = first
+    """conv1.weight [64][3][7][7] and the folded BatchNorm scale [64] -> wpack of rpg_stem_conv7x7s2_bn_relu_maxpool_f32, two operand
+    images back to back ([74][2][64] for the tile kernel, then [2][75][64] for the strip-march kernel): element [kp][nf][l] = scale[ch] * W[ch][tap], ch = 32 nf + (l & 31), tap = first
     (l < 32) or second (l >= 32) tap of pair kp (0 for the missing partner of the last pair)."""
     if tuple(w_oihw.shape) != (64, 3, 7, 7):
         raise ValueError("the fused stem kernel is for Conv2d(3, 64, 7)")
@@ -74,7 +74,27 @@ def pack_stem_pairs(w_oihw: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
     wa = torch.stack([w[:, c, kh, kw] for c, kh, kw in a])                                   # [74][64]
     wb = torch.stack([w[:, t[0], t[1], t[2]] if t is not None else torch.zeros_like(w[:, 0, 0, 0]) for t in b])
     out = torch.stack([wa.view(74, 2, 32), wb.view(74, 2, 32)], dim=2)                       # [74][nf][half][32]
-    return out.reshape(74, 2, 64).contiguous()
+    tile = out.reshape(74 * 2 * 64)
+    # second part (round 6, the strip-march kernel stem_strip_f32_kernel): [nf][75][l = 32 half + n]: per kernel row kh the three
+    # horizontal pairs (kw 2p | 2p + 1) of the three channels, after an odd kh the vertical pairs (kh - 1 | kh, kw = 6), after kh = 6
+    # the lone (6, 6) taps -- the order the kernel issues its MFMAs in
+    zero = torch.zeros_like(w[:, 0, 0, 0])
+    sa, sb = [], []
+    for kh in range(7):
+        for c in range(3):
+            for p_ in range(3):
+                sa.append(w[:, c, kh, 2 * p_]); sb.append(w[:, c, kh, 2 * p_ + 1])
+        if kh & 1:
+            for c in range(3):
+                sa.append(w[:, c, kh - 1, 6]); sb.append(w[:, c, kh, 6])
+        if kh == 6:
+            for c in range(3):
+                sa.append(w[:, c, 6, 6]); sb.append(zero)
+    assert len(sa) == 75
+    sa, sb = torch.stack(sa), torch.stack(sb)                                                 # [75][64 ch]
+    strip = torch.stack([sa.view(75, 2, 32), sb.view(75, 2, 32)], dim=2)                      # [75][nf][half][32]
+    strip = strip.permute(1, 0, 2, 3).reshape(2 * 75 * 64)                                    # [nf][75][half][32]
+    return torch.cat([tile, strip]).contiguous()
 
 
 def resnet_structure(sd: Dict[str, torch.Tensor], prefix: str) -> Tuple[List[int], List[int]]:

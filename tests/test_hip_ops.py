@@ -75,11 +75,25 @@ def test_conv_transpose_detecting(dev):
     assert rel_err(y.cpu().permute(0, 3, 1, 2), ref) < 1e-6
 
 
-@pytest.mark.parametrize("n,h,w", [(2, 224, 224), (1, 256, 341), (3, 64, 64), (2, 37, 53), (1, 7, 9), (1, 450, 600), (5, 32, 40)])
-def test_fused_stem_conv_bn_relu_maxpool(dev, n, h, w):
+@pytest.mark.parametrize("kernel", [1, 1 + 128, 1 + 128 + (7 << 8), 1 + 128 + (3 << 8)])      # RPG_TUNE_FUSED_STEM: tile kernel (default), strip-march kernel (bit 7: default bands / 7- / 3-row bands)
+@pytest.mark.parametrize("n,h,w", [(2, 224, 224), (1, 256, 341), (3, 64, 64), (2, 37, 53), (1, 7, 9), (1, 450, 600), (5, 32, 40), (1, 1, 1), (9, 250, 123),
+                                   (2, 30, 130)])
+def test_fused_stem_conv_bn_relu_maxpool(dev, n, h, w, kernel):
     """rpg_stem_conv7x7s2_bn_relu_maxpool_f32 vs conv2d(7x7, s2, p3) -> BN affine -> ReLU -> max_pool2d(3, 2, 1) (the
     torchvision stem reached from posenet.py:1037): 224x224 (one column tile of 56), the 256x341 evaluation shape (two
-    column tiles), odd / tiny sizes (ragged tiles, all-border tiles) and a wide image (three column tiles)."""
+    column tiles), odd / tiny sizes (ragged tiles, all-border tiles) and a wide image (three column tiles).
+    Round 6: also the strip-march kernel (opt-in, bit 7; csrc/stem.hip stem_strip_f32_kernel: strips of 15 pooled columns, bands of
+    pooled rows, odd convolution heights and widths, images narrower than a strip)."""
+    from relpose_gnn_amd import ops
+    from relpose_gnn_amd.params import pack_stem_pairs
+    ops.set_tuning(ops.TUNE_FUSED_STEM, kernel)
+    try:
+        _fused_stem_f32_case(dev, n, h, w)
+    finally:
+        ops.set_tuning(ops.TUNE_FUSED_STEM, 1)
+
+
+def _fused_stem_f32_case(dev, n, h, w):
     from relpose_gnn_amd import ops
     from relpose_gnn_amd.params import pack_stem_pairs
     x = _rand(n, 3, h, w, seed=h)

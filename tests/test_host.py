@@ -203,8 +203,15 @@ def test_stem_pair_table_matches_the_kernel():
     assert taps == sorted((c, kh, kw) for c in range(3) for kh in range(7) for kw in range(7))      # every tap exactly once
     w = torch.arange(64 * 147, dtype=torch.float32).view(64, 3, 7, 7)
     sc = torch.full((64,), 2.0)
-    wp = pack_stem_pairs(w, sc)
-    assert wp.shape == (74, 2, 64)
+    wp_all = pack_stem_pairs(w, sc)
+    assert wp_all.shape == ((74 + 75) * 2 * 64,)                                                    # tile-kernel image, then the strip-march image
+    wp = wp_all[:74 * 2 * 64].view(74, 2, 64)
+    st = wp_all[74 * 2 * 64:].view(2, 75, 64)                                                       # [nf][MFMA of a convolution row][lane]
+    # strip image: kernel row 0, channel 1, horizontal pair 2 = entry 3 * 1 + 2: taps (1, 0, 4) | (1, 0, 5); entry 9 * 1 + 9 + 2 = the
+    # vertical pair (kh 0 | 1, kw 6) of channel 2; the last three entries are the lone (6, 6) taps with a zero partner
+    assert float(st[1, 5, 7]) == 2.0 * float(w[39, 1, 0, 4]) and float(st[1, 5, 32 + 7]) == 2.0 * float(w[39, 1, 0, 5])
+    assert float(st[0, 20, 3]) == 2.0 * float(w[3, 2, 0, 6]) and float(st[0, 20, 32 + 3]) == 2.0 * float(w[3, 2, 1, 6])
+    assert float(st[0, 74, 3]) == 2.0 * float(w[3, 2, 6, 6]) and float(st[0, 74, 32 + 3]) == 0.0
     assert float(wp[5, 1, 7]) == 2.0 * float(w[39, a[5][0], a[5][1], a[5][2]])                      # first tap, channel 32 + 7
     assert float(wp[5, 1, 32 + 7]) == 2.0 * float(w[39, b[5][0], b[5][1], b[5][2]])                # second tap
     assert float(wp[73, 0, 40]) == 0.0                                                              # the missing partner

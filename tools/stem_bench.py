@@ -39,8 +39,12 @@ def timeit(fn, reps=20):
 if not bf16:
     wp = pack_stem_pairs(wt, torch.ones(64)).to(dev)
     sh = torch.zeros(64, device=dev)
-    med, best = timeit(lambda: ops.stem_conv_bn_relu_maxpool(x, wp, sh))
-    print(f"fp32 stem n={n} {h}x{w}: median {med*1e3:.1f} us  best {best*1e3:.1f} us   {flop/med/1e9:.1f} TFLOP/s algorithmic")
+    for name, val in (("tile kernel (default)", 1), ("strips", 129), ("strips, bands of 7", 129 + (7 << 8)), ("strips, bands of 14", 129 + (14 << 8)),
+                      ("strips, bands of 28", 129 + (28 << 8)), ("tile kernel (default)", 1), ("strips", 129)):
+        ops.set_tuning(ops.TUNE_FUSED_STEM, val)
+        med, best = timeit(lambda: ops.stem_conv_bn_relu_maxpool(x, wp, sh))
+        print(f"fp32 stem n={n} {h}x{w} {name:24s}: median {med*1e3:7.1f} us  best {best*1e3:7.1f} us   {flop/med/1e9:6.1f} TFLOP/s algorithmic", flush=True)
+    ops.set_tuning(ops.TUNE_FUSED_STEM, 1)
 else:
     wp = pack_stem_bf16(wt).to(dev)
     sc, sh = torch.rand(64, device=dev) + 0.5, torch.zeros(64, device=dev)
