@@ -1627,6 +1627,11 @@ int launch_conv_bf16(const void* x, const void* w, const float* scale, const flo
         };
         if (g_bf16_patch == 3) {
             done = launch_patch<256, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s);
+        } else if (g_bf16_patch == 4 && cout > 128) {
+            // round-6 experiment (RPG_TUNE_BF16_PATCH = 4): 512 x 128 tiles on the 256- / 512-channel layers too -- 15 instead of 21 bytes of
+            // L2 -> LDS fill per output.  Measured at 512 images: layer 3 124-127 us against 127-130, layer 4 126-137 against 119-123: the
+            // fill volume is not what bounds these layers either
+            done = launch_patch<512, 128, 4, 2, 4>(a, wp, n, (int)M, cout, ep, s) || launch_patch<512, 128, 4, 2, 3>(a, wp, n, (int)M, cout, ep, s);
         } else if (cout > 128 && 4 * t256 >= 3L * num_cus()) {
             const int m_main = (g_bf16_tail & 2) && cout <= 256 ? tail_split(256, 160) : 0;
             done = (g_bf16_stages != 3 && launch_patch<256, 256, 2, 4, 4>(a, wp, n, (int)M, cout, ep, s, 0, m_main)) ||

@@ -803,7 +803,7 @@ extern "C" int rpg_set_tuning(int key, int value) {
             if (value < 0) return RPG_ERR_BAD_ARG;
             rpg::bf16_set_chunk(value & 4095, (value >> 12) ? (value >> 12) : 64);
             return RPG_OK;
-        case RPG_TUNE_BF16_PATCH: if (value < 0 || value % 10 > 3 || value > 13) return RPG_ERR_BAD_ARG; rpg::bf16_set_patch(value); return RPG_OK;
+        case RPG_TUNE_BF16_PATCH: if (value < 0 || value % 10 > 4 || value > 14) return RPG_ERR_BAD_ARG; rpg::bf16_set_patch(value); return RPG_OK;
         case RPG_TUNE_BF16_DMA: if (value < 0 || value > 40) return RPG_ERR_BAD_ARG; rpg::bf16_set_dma(value); return RPG_OK;
         case RPG_TUNE_SK_MIN_ITS: if (value < 1 || value > 4096) return RPG_ERR_BAD_ARG; SK_MIN_ITS = value; return RPG_OK;
         case RPG_TUNE_BF16_WS64: if (value < 0 || value > 2) return RPG_ERR_BAD_ARG; return rpg::bf16_set_ws64(value);

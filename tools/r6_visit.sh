@@ -1,3 +1,6 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6s; mkdir -p $OUT
-timeout 1500 python -m pytest tests/test_hip_ops.py tests/test_hip_bench_geometry.py -q -m gpu -x > $OUT/pytest.log 2>&1; echo "rc=$?" >> $OUT/pytest.log; tail -3 $OUT/pytest.log
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6t; mkdir -p $OUT
+for t in 1 4 1 4; do
+timeout 300 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --only l3.c --tune 17=$t 2>&1 | grep conv
+timeout 300 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --only l4.c --tune 17=$t 2>&1 | grep conv
+done
