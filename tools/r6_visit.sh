@@ -1,6 +1,4 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6t; mkdir -p $OUT
-for t in 1 4 1 4; do
-timeout 300 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --only l3.c --tune 17=$t 2>&1 | grep conv
-timeout 300 python tools/conv_bench.py --bf16 --nimg 512 --warm 3 --only l4.c --tune 17=$t 2>&1 | grep conv
-done
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6u; mkdir -p $OUT
+bash tools/gpu_check.sh r6u > $OUT/gpu_check.log 2>&1; tail -6 $OUT/gpu_check.log | cut -c1-400
+bash tools/collect_profiles.sh r6b > $OUT/collect.log 2>&1; tail -3 $OUT/collect.log
