@@ -44,6 +44,10 @@ LINEAR = [  # name, m, widths, n_out
     ("nd128.node3", 128, (2048,), 6144),
     ("nd128.upd0", 128, (2048, 2048), 2048),
     ("nd128.upd2", 128, (2048,), 2048),
+    # round 6: what a four-way split-K of the attention projections on exact-fit 112 x 64 tiles would cost --
+    # the same 768 work items of 16 K steps each, emulated as ONE Linear of 4 x 1792 rows and K = 512 (then + a fix-up launch)
+    ("gtp.splitk4_emulated", 4 * 1792, (512,), 768),
+    ("gtp.splitk2_emulated", 2 * 1792, (1024,), 768),
 ]
 
 

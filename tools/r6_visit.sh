@@ -1,4 +1,4 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6u; mkdir -p $OUT
-bash tools/gpu_check.sh r6u > $OUT/gpu_check.log 2>&1; tail -6 $OUT/gpu_check.log | cut -c1-400
-bash tools/collect_profiles.sh r6b > $OUT/collect.log 2>&1; tail -3 $OUT/collect.log
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6v; mkdir -p $OUT
+timeout 300 python tools/conv_bench.py --warm 3 --only gtp > $OUT/gtp.txt 2>&1; grep lin $OUT/gtp.txt
+timeout 300 python tools/conv_bench.py --warm 3 --only gtp --tune 29=0 >> $OUT/gtp.txt 2>&1; grep lin $OUT/gtp.txt | tail -3
