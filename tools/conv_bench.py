@@ -48,6 +48,12 @@ LINEAR = [  # name, m, widths, n_out
     # the same 768 work items of 16 K steps each, emulated as ONE Linear of 4 x 1792 rows and K = 512 (then + a fix-up launch)
     ("gtp.splitk4_emulated", 4 * 1792, (512,), 768),
     ("gtp.splitk2_emulated", 2 * 1792, (1024,), 768),
+    # ... and the algebraic merge (the projections as 768 more output columns of mlp.2's GEMM, weight product precomputed)
+    ("gtp.merged_with_msg2", 1792, (2048,), 2816),
+    ("gtp.msg2_alone", 1792, (2048,), 2048),
+    ("gtp.m896", 896, (2048,), 768),
+    ("gtp.m896_merged_with_msg2", 896, (2048,), 2816),
+    ("gtp.m896_msg2_alone", 896, (2048,), 2048),
 ]
 
 
