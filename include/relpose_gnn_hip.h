@@ -328,10 +328,10 @@ int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* ex
 #define RPG_TUNE_WAVES8 11        /* 1: 8-wave workgroups (two waves per SIMD) for the 128x128 / 128x64 tiles of the f32 tile engine where
                                      the buffer-load path applies (default) | 0: always 4-wave workgroups */
 #define RPG_TUNE_FUSED_STEM 10    /* bit 0: one-kernel stem (conv7x7 + BN + ReLU + max-pool) where its operands are given (default 1) | 0: three kernels.
-                                     bf16 stem only: bit 1 = the tile kernel of rounds 3-5 instead of the strip-march kernel of round 6; variants of the
-                                     strip-march kernel (none of these bits: the default, bit 3): bit 3 = both 32-channel halves in one wave, weights in
-                                     LDS, two waves per SIMD; bit 5 = one half per wave, weights in LDS, three waves per SIMD; bit 2 = one half per wave,
-                                     weights in registers, two waves; bit 4 = one half per wave, four waves per SIMD; value >> 8 = pooled rows per band
+                                     bf16 stem only: bit 1 = the tile kernel of rounds 3-5 instead of the strip-march kernel of round 6; bit 5 = the
+                                     strip-march kernel with one 32-channel half per wave and three waves per SIMD (default: both halves in one wave,
+                                     two waves per SIMD; the register-weight and four-wave variants were measured slower and removed); value >> 8 =
+                                     pooled rows per band
                                      (0, the default: by the launch's size).  fp32 stem: bit 7 = the strip-march kernel (round 6; opt-in: 6-12 % faster
                                      than the tile kernel, every fp32 bar holds, but it re-rolls the rounding noise of the noise-floor ratio test) */
 #define RPG_TUNE_WINO_SPLIT 8     /* 1: split-K tail + fix-up for the 8-wave Winograd kernel (default) | 0: whole tiles only | n >= 2: as 1, and a part of a

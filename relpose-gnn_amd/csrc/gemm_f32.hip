@@ -807,7 +807,7 @@ extern "C" int rpg_set_tuning(int key, int value) {
         case RPG_TUNE_BF16_DMA: if (value < 0 || value > 40) return RPG_ERR_BAD_ARG; rpg::bf16_set_dma(value); return RPG_OK;
         case RPG_TUNE_SK_MIN_ITS: if (value < 1 || value > 4096) return RPG_ERR_BAD_ARG; SK_MIN_ITS = value; return RPG_OK;
         case RPG_TUNE_BF16_WS64: if (value < 0 || value > 2) return RPG_ERR_BAD_ARG; return rpg::bf16_set_ws64(value);
-        case RPG_TUNE_FUSED_STEM: rpg::stem_pool_set((value & 1) != 0); rpg::stem_pool_set_strip((value & 128) != 0, value >> 8); rpg::bf16_set_fused_stem((value & 1) != 0); rpg::bf16_set_stem_strip((value & 2) ? 0 : ((value & 0x3c) ? (1 | (value & 0x1c)) : 9), value >> 8); return RPG_OK;
+        case RPG_TUNE_FUSED_STEM: rpg::stem_pool_set((value & 1) != 0); rpg::stem_pool_set_strip((value & 128) != 0, value >> 8); rpg::bf16_set_fused_stem((value & 1) != 0); rpg::bf16_set_stem_strip((value & 2) ? 0 : ((value & 32) ? 1 : 9), value >> 8); return RPG_OK;
         case RPG_TUNE_WINOGRAD: if (value < 0 || (value > 3 && value < 16)) return RPG_ERR_BAD_ARG; rpg::wino_set(value); return RPG_OK;
         case RPG_TUNE_WINO_PERSIST: if (value < 0 || value > 2) return RPG_ERR_BAD_ARG; rpg::wino_persist_set(value); return RPG_OK;
         case RPG_TUNE_WINO_SHORT: if (value < 0) return RPG_ERR_BAD_ARG; rpg::wino_short_set(value); return RPG_OK;

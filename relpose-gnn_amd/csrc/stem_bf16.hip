@@ -277,24 +277,22 @@ struct StemSArgs {
     unsigned items;        // N * bands * tiles_x * (2 / NF)
 };
 
-// WLDS: the weights live in LDS (24 KB per workgroup, one ds_read_b128 per MFMA) and the kernel fits three waves per SIMD;
-// !WLDS: in registers (48 VGPRs), two waves per SIMD.
-// NF: 32-channel halves per wave (1: two work items per strip, three waves per SIMD with the weights in LDS; 2: one item per strip --
-// half the input loads and conversions per MFMA, two accumulator chains, two waves per SIMD).
-template <typename TIn, bool WLDS, int NF, int WPE = ((WLDS && NF == 1) ? 3 : 2)>
-__global__ __launch_bounds__(SS_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void stem_strip_bf16_kernel(StemSArgs a) {
+// NF: 32-channel halves per wave (2, the default: one work item per strip -- half the input loads and conversions per MFMA, two
+// accumulator chains, two waves per SIMD; 1: two work items per strip, three waves per SIMD).  The weights live in LDS (24 KB per
+// workgroup, one ds_read_b128 per MFMA, read two MFMAs ahead).  Measured and removed again (profiles/r6_stem_bf16_variants.txt, 512
+// images): the weights in 48 registers instead of LDS (264 us against 255 for NF = 1), four waves per SIMD (260).
+template <typename TIn, int NF>
+__global__ __launch_bounds__(SS_NT) __attribute__((amdgpu_waves_per_eu(NF == 1 ? 3 : 2, NF == 1 ? 3 : 2))) void stem_strip_bf16_kernel(StemSArgs a) {
     constexpr int ESZ = (int)sizeof(TIn);
     constexpr int NLD = ESZ == 4 ? 2 : 1;                 // 16-byte loads per 8-column window
     constexpr unsigned SENT = 0x80000000u;
     __shared__ __attribute__((aligned(16))) float aff[128];
     const int tid = threadIdx.x, lane = tid & 63, l = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    __shared__ uint4 wl[WLDS ? 2 * 12 * 64 : 1];
+    __shared__ uint4 wl[2 * 12 * 64];
     if (tid < 128) aff[tid] = tid < 64 ? a.scale[tid] : a.shift[tid - 64];
-    if constexpr (WLDS) {
 #pragma unroll
-        for (int i = 0; i < 2 * 12 * 64 / SS_NT; ++i) wl[tid + i * SS_NT] = a.wpack[tid + i * SS_NT];
-    }
+    for (int i = 0; i < 2 * 12 * 64 / SS_NT; ++i) wl[tid + i * SS_NT] = a.wpack[tid + i * SS_NT];
     __syncthreads();
     // workgroups b and b + 8 sit on the same XCD: give them neighbouring items (the strips of one band share their input rows)
     const unsigned b = blockIdx.x, nb = gridDim.x;
@@ -341,18 +339,9 @@ __global__ __launch_bounds__(SS_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                                                                                      //  of the next image / of the allocation's padding)
 
     // ---- weights: A operands, resident
-    static_assert(WLDS || NF == 1, "register weights: one 32-channel half per wave");
-    bf16x8 wreg[WLDS ? 1 : 3][WLDS ? 1 : 4];
-    if constexpr (!WLDS) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wreg[c][j] = __builtin_bit_cast(bf16x8, a.wpack[((nf * 3 + c) * 4 + j) * 64 + lane]);
-    }
-    const uint4* const wl_lane = wl + (WLDS ? nf * 12 * 64 + lane : 0);
+    const uint4* const wl_lane = wl + nf * 12 * 64 + lane;
     auto weight = [&](int f, int k) -> bf16x8 {           // fragment of half nf + f, MFMA k = 4 c + j
-        if constexpr (WLDS) return __builtin_bit_cast(bf16x8, wl_lane[(f * 12 + k) * 64]);
-        else return wreg[k / 4][k % 4];
+        return __builtin_bit_cast(bf16x8, wl_lane[(f * 12 + k) * 64]);
     };
 
     bf16x8 op[3][4];                                      // pixel operands; logical pair j of row oy lives in slot (j + oy) & 3
@@ -450,9 +439,8 @@ __global__ __launch_bounds__(SS_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
 #define RPG_SS_MFMA(K, R)                                                                                                      \
     do {                                                                                                                       \
         _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                                       \
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WLDS ? wf[f][(K) % 3] : wreg[WLDS ? 0 : (K) / 4][WLDS ? 0 : (K) % 4], \
-                                                             op[(K) / 4][(((K) % 4) + (R)) & 3], acc[f], 0, 0, 0);             \
-            if (WLDS && (K) + 2 < 12) wf[f][((K) + 2) % 3] = weight(f, (K) + 2);                                               \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[f][(K) % 3], op[(K) / 4][(((K) % 4) + (R)) & 3], acc[f], 0, 0, 0); \
+            if ((K) + 2 < 12) wf[f][((K) + 2) % 3] = weight(f, (K) + 2);                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                                                 \
         }                                                                                                                      \
     } while (0)
@@ -465,7 +453,7 @@ __global__ __launch_bounds__(SS_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             bf16x8 wf[NF][3];                                                                                                  \
             _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                                   \
                 _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;                                                \
-                if (WLDS) { wf[f][0] = weight(f, 0); wf[f][1] = weight(f, 1); }                                                \
+                wf[f][0] = weight(f, 0); wf[f][1] = weight(f, 1);                                                              \
             }                                                                                                                  \
             __builtin_amdgcn_sched_barrier(0);                                                                                 \
             RPG_SS_MFMA(0, R); RPG_SS_MFMA(1, R); RPG_SS_MFMA(2, R); RPG_SS_MFMA(3, R);                                        \
@@ -535,7 +523,7 @@ static bool stem_pool_bf16_geometry(int n, int h, int w, StemBArgs& a, int& grid
 int g_stem_strip = 9;          // 0: the tile kernel (rounds 3-5) | bit 0: the strip-march kernel of round 6, + bit 3 (default): both 32-channel halves in
                                // one wave (measured at 512 images, profiles/r6_stem_bf16_variants.txt: 227 us against 255-265 with one half per wave
                                // and three waves per SIMD -- the texture addresser was 72 % busy with every input window loaded by two waves --,
-                               // 264 with the weights in registers (bit 2), 260 with four waves per SIMD (bit 4), 375 for the tile kernel)
+                               // 375 for the tile kernel)
 int g_stem_strip_bh = 0;       // pooled rows per band (RPG_TUNE_FUSED_STEM value >> 4, experiments); 0 = by the launch's size
 void bf16_set_stem_strip(int mode, int bh) { g_stem_strip = mode; g_stem_strip_bh = bh > 0 ? bh : 0; }
 
@@ -553,7 +541,7 @@ static bool stem_strip_geometry(int n, int h, int w, int esz, StemSArgs& a, int&
         // pooled rows, 270 with 4 of 14, 283 with 8 of 7), short ones fill the chip when there are few images: the fewest bands that
         // still give two rounds of workgroups (768 resident: 256 CUs x 3), never shorter than 7 pooled rows
         int bands = 1;
-        while ((long)n * bands * a.tiles_x * (g_stem_strip & 8 ? 1 : 2) / 4 < 2 * (g_stem_strip & 8 ? 2L : (g_stem_strip & 16 ? 4L : 3L)) * num_cus() && (a.Hp + 2 * bands - 1) / (2 * bands) >= 7) bands *= 2;
+        while ((long)n * bands * a.tiles_x * (g_stem_strip & 8 ? 1 : 2) / 4 < 2 * (g_stem_strip & 8 ? 2L : 3L) * num_cus() && (a.Hp + 2 * bands - 1) / (2 * bands) >= 7) bands *= 2;
         a.BH = (a.Hp + bands - 1) / bands;
     }
     a.bands = (a.Hp + a.BH - 1) / a.BH;
@@ -583,18 +571,12 @@ int launch_stem_pool_bf16(const void* x_nchw, int x_is_bf16, const void* wpack, 
             sa.x = x_nchw; sa.scale = scale; sa.shift = shift; sa.out = reinterpret_cast<__bf16*>(out);
             sa.wpack = reinterpret_cast<const uint4*>(wpack) + KS * NF * 64;       // second part of params.pack_stem_bf16
             const int slot = timing_begin(RPG_TIMER_CONV, s);
-            if (g_stem_strip & 16) {
-                if (x_is_bf16) hipLaunchKernelGGL((stem_strip_bf16_kernel<__bf16, true, 1, 4>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
-                else hipLaunchKernelGGL((stem_strip_bf16_kernel<float, true, 1, 4>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
-            } else if (g_stem_strip & 8) {
-                if (x_is_bf16) hipLaunchKernelGGL((stem_strip_bf16_kernel<__bf16, true, 2>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
-                else hipLaunchKernelGGL((stem_strip_bf16_kernel<float, true, 2>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
-            } else if (g_stem_strip & 4) {
-                if (x_is_bf16) hipLaunchKernelGGL((stem_strip_bf16_kernel<__bf16, false, 1>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
-                else hipLaunchKernelGGL((stem_strip_bf16_kernel<float, false, 1>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+            if (g_stem_strip & 8) {
+                if (x_is_bf16) hipLaunchKernelGGL((stem_strip_bf16_kernel<__bf16, 2>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+                else hipLaunchKernelGGL((stem_strip_bf16_kernel<float, 2>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
             } else {
-                if (x_is_bf16) hipLaunchKernelGGL((stem_strip_bf16_kernel<__bf16, true, 1>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
-                else hipLaunchKernelGGL((stem_strip_bf16_kernel<float, true, 1>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+                if (x_is_bf16) hipLaunchKernelGGL((stem_strip_bf16_kernel<__bf16, 1>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
+                else hipLaunchKernelGGL((stem_strip_bf16_kernel<float, 1>), dim3(sgrid), dim3(SS_NT), 0, s, sa);
             }
             // executed: per item 2 np + 1 convolution rows x 12 MFMAs of 32 x 32 x 16
             timing_end(slot, 2.0 * (double)n * sa.Hc * sa.Wc * 64.0 * 147.0, s,

@@ -370,7 +370,7 @@ def test_conv_bf16_lean_epilogue_equals_general(dev, n, h, w, cin, cout, k, stri
     assert float((got - ref).abs().mean() / ref.abs().mean().clamp(min=1e-30)) < 3e-3
 
 
-@pytest.mark.parametrize("kernel", [1, 5, 33, 17, 1 + (7 << 8), 33 + (14 << 8), 3])       # RPG_TUNE_FUSED_STEM: strip-march kernel (default: both halves per wave / weights in registers / one half per wave, LDS / four waves per SIMD / 7- and 14-row bands), tile kernel
+@pytest.mark.parametrize("kernel", [1, 33, 1 + (7 << 8), 33 + (14 << 8), 3])       # RPG_TUNE_FUSED_STEM: strip-march kernel (default: both halves per wave / one half per wave / 7- and 14-row bands), tile kernel
 @pytest.mark.parametrize("n,h,w", [(2, 224, 224), (1, 256, 341), (3, 37, 53), (2, 9, 5), (1, 64, 500), (5, 32, 40), (1, 1, 1), (70, 64, 72),
                                    (67, 40, 24), (2, 250, 123), (1, 30, 130)])
 def test_fused_stem_bf16(dev, n, h, w, kernel):

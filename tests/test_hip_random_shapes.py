@@ -206,7 +206,7 @@ def test_random_stem_bf16_strips(dev, case):
     from relpose_gnn_amd.params import pack_stem_bf16
     rng = random.Random(4000 + case)
     n, h, w = rng.randint(1, 9), rng.randint(1, 150), rng.randint(1, 260)
-    variant = rng.choice([1, 33, 5, 17]) + (rng.choice([0, 3, 7, 11]) << 8)
+    variant = rng.choice([1, 33]) + (rng.choice([0, 3, 7, 11]) << 8)
     x = _rand(n, 3, h, w, seed=case)
     wt = _rand(64, 3, 7, 7, seed=case + 1, scale=(2.0 / 147) ** 0.5)
     g = torch.Generator().manual_seed(case + 2)

@@ -50,9 +50,8 @@ else:
     sc, sh = torch.rand(64, device=dev) + 0.5, torch.zeros(64, device=dev)
     xb = x.bfloat16()
     only = next((sys.argv[i + 1] for i, a in enumerate(sys.argv) if a == "--variants"), "")
-    for name, val in (("tile kernel (r3-r5)", 3), ("strips, default (both halves per wave)", 1), ("strips, one half per wave, LDS weights, 3 waves/SIMD", 33),
-                      ("strips, one half, register weights", 5), ("strips, one half, 4 waves/SIMD", 17), ("strips, default, bands of 14", 1 + (14 << 8)),
-                      ("strips, default, bands of 56", 1 + (56 << 8))):
+    for name, val in (("tile kernel (r3-r5)", 3), ("strips, default (both halves per wave)", 1), ("strips, one half per wave, 3 waves/SIMD", 33),
+                      ("strips, default, bands of 14", 1 + (14 << 8)), ("strips, default, bands of 56", 1 + (56 << 8))):
         if only and only not in name:
             continue
         ops.set_tuning(ops.TUNE_FUSED_STEM, val)
