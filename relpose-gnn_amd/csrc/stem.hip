@@ -515,6 +515,26 @@ static int g_stem_f32_strip = 0;                 // RPG_TUNE_FUSED_STEM bit 7 se
 static int g_stem_f32_bh = 0;                    // pooled rows per band (0: by the launch's size)
 void stem_pool_set_strip(int on, int bh) { g_stem_f32_strip = on; g_stem_f32_bh = bh > 0 ? bh : 0; }
 
+// Pooled rows per band of a strip-march launch: a band costs one extra convolution row and three warm-up row loads (~1.5 rows), so
+// long bands are cheap -- but the launch should fill whole rounds of the resident workgroup slots (`slots` = CUs x workgroups per CU;
+// measured round 6, both-halves form: 512 images best with 1 band, 256 with 2, 128 with 4, 64 with 8 -- always exactly one round).
+// Picks the band count with the best (round occupancy) x (band overhead) x (ragged last band), fewest bands on ties.
+static int strip_band_rows(long items_per_band, int hp, long slots) {
+    int best_bh = hp;
+    double best = -1.0;
+    for (int bands = 1; bands <= hp; ++bands) {
+        const int bh = (hp + bands - 1) / bands;
+        if (bh < 7 && bands > 1) break;
+        const int nb = (hp + bh - 1) / bh;
+        if (nb != bands) continue;                          // (the same band height as a smaller count already tried)
+        const long wgs = (items_per_band * nb + 3) / 4;
+        const long rounds = (wgs + slots - 1) / slots;
+        const double eff = (double)wgs / (double)(rounds * slots) * (2.0 * bh / (2.0 * bh + 2.5)) * ((double)hp / (double)(nb * bh));
+        if (eff > best + 1e-9) { best = eff; best_bh = bh; }
+    }
+    return best_bh;
+}
+
 int launch_stem_pool(const float* x_nchw, const float* wpack, const float* shift, float* out, int n, int h, int w,
                      hipStream_t s) {
     if (!x_nchw || !wpack || !shift || !out || n <= 0 || h <= 0 || w <= 0 || !aligned16(out)) return RPG_ERR_BAD_ARG;
@@ -529,10 +549,7 @@ int launch_stem_pool(const float* x_nchw, const float* wpack, const float* shift
         if (g_stem_f32_bh > 0) {
             sa.BH = g_stem_f32_bh < sa.Hp ? g_stem_f32_bh : sa.Hp;
         } else {
-            // the fewest bands that give two rounds of workgroups (2 per CU), never shorter than 7 pooled rows
-            int bands = 1;
-            while ((long)n * bands * sa.tiles_x * 2 / 4 < 2 * 2L * num_cus() && (sa.Hp + 2 * bands - 1) / (2 * bands) >= 7) bands *= 2;
-            sa.BH = (sa.Hp + bands - 1) / bands;
+            sa.BH = strip_band_rows((long)n * sa.tiles_x * 2, sa.Hp, 2L * num_cus());
         }
         sa.bands = (sa.Hp + sa.BH - 1) / sa.BH;
         const long items = (long)n * sa.bands * sa.tiles_x * 2;

@@ -527,6 +527,26 @@ int g_stem_strip = 9;          // 0: the tile kernel (rounds 3-5) | bit 0: the s
 int g_stem_strip_bh = 0;       // pooled rows per band (RPG_TUNE_FUSED_STEM value >> 4, experiments); 0 = by the launch's size
 void bf16_set_stem_strip(int mode, int bh) { g_stem_strip = mode; g_stem_strip_bh = bh > 0 ? bh : 0; }
 
+// Pooled rows per band of a strip-march launch: a band costs one extra convolution row and three warm-up row loads (~1.5 rows), so
+// long bands are cheap -- but the launch should fill whole rounds of the resident workgroup slots (`slots` = CUs x workgroups per CU;
+// measured round 6, both-halves form: 512 images best with 1 band, 256 with 2, 128 with 4, 64 with 8 -- always exactly one round).
+// Picks the band count with the best (round occupancy) x (band overhead) x (ragged last band), fewest bands on ties.
+static int strip_band_rows(long items_per_band, int hp, long slots) {
+    int best_bh = hp;
+    double best = -1.0;
+    for (int bands = 1; bands <= hp; ++bands) {
+        const int bh = (hp + bands - 1) / bands;
+        if (bh < 7 && bands > 1) break;
+        const int nb = (hp + bh - 1) / bh;
+        if (nb != bands) continue;                          // (the same band height as a smaller count already tried)
+        const long wgs = (items_per_band * nb + 3) / 4;
+        const long rounds = (wgs + slots - 1) / slots;
+        const double eff = (double)wgs / (double)(rounds * slots) * (2.0 * bh / (2.0 * bh + 2.5)) * ((double)hp / (double)(nb * bh));
+        if (eff > best + 1e-9) { best = eff; best_bh = bh; }
+    }
+    return best_bh;
+}
+
 static bool stem_strip_geometry(int n, int h, int w, int esz, StemSArgs& a, int& grid) {
     if (n <= 0 || h <= 0 || w <= 0) return false;
     a.N = n; a.H = h; a.W = w;
@@ -537,12 +557,7 @@ static bool stem_strip_geometry(int n, int h, int w, int esz, StemSArgs& a, int&
     if (g_stem_strip_bh > 0) {
         a.BH = g_stem_strip_bh < a.Hp ? g_stem_strip_bh : a.Hp;
     } else {
-        // long bands amortise a band's extra convolution row and its three warm-up row loads (512 images: 259 us with 2 bands of 28
-        // pooled rows, 270 with 4 of 14, 283 with 8 of 7), short ones fill the chip when there are few images: the fewest bands that
-        // still give two rounds of workgroups (768 resident: 256 CUs x 3), never shorter than 7 pooled rows
-        int bands = 1;
-        while ((long)n * bands * a.tiles_x * (g_stem_strip & 8 ? 1 : 2) / 4 < 2 * (g_stem_strip & 8 ? 2L : 3L) * num_cus() && (a.Hp + 2 * bands - 1) / (2 * bands) >= 7) bands *= 2;
-        a.BH = (a.Hp + bands - 1) / bands;
+        a.BH = strip_band_rows((long)n * a.tiles_x * (g_stem_strip & 8 ? 1 : 2), a.Hp, (g_stem_strip & 8 ? 2L : 3L) * num_cus());
     }
     a.bands = (a.Hp + a.BH - 1) / a.BH;
     const long items = (long)n * a.bands * a.tiles_x * (g_stem_strip & 8 ? 1 : 2);        // bit 3: both channel halves in one wave

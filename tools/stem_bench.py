@@ -24,7 +24,7 @@ flop = 2.0 * n * hc * wc * 64 * 147
 
 
 def timeit(fn, reps=20):
-    for _ in range(3):
+    for _ in range(40):            # (clock ramp: a cold GPU runs these kernels up to 25 % slower for the first dozen launches)
         fn()
     torch.cuda.synchronize()
     ts = []
@@ -51,7 +51,8 @@ else:
     xb = x.bfloat16()
     only = next((sys.argv[i + 1] for i, a in enumerate(sys.argv) if a == "--variants"), "")
     for name, val in (("tile kernel (r3-r5)", 3), ("strips, default (both halves per wave)", 1), ("strips, one half per wave, 3 waves/SIMD", 33),
-                      ("strips, default, bands of 14", 1 + (14 << 8)), ("strips, default, bands of 56", 1 + (56 << 8))):
+                      ("strips, default, bands of 7", 1 + (7 << 8)), ("strips, default, bands of 14", 1 + (14 << 8)), ("strips, default, bands of 28", 1 + (28 << 8)),
+                      ("strips, default, bands of 56", 1 + (56 << 8))):
         if only and only not in name:
             continue
         ops.set_tuning(ops.TUNE_FUSED_STEM, val)
