@@ -1,4 +1,4 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6z; mkdir -p $OUT
-bash tools/gpu_check.sh r6z > $OUT/gpu_check.log 2>&1; tail -6 $OUT/gpu_check.log | cut -c1-300
-bash tools/collect_profiles.sh r6c > $OUT/collect.log 2>&1; tail -3 $OUT/collect.log
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6aa; mkdir -p $OUT
+timeout 300 python tools/conv_bench.py --bf16 --block64 --nimg 512 --warm 10 2>&1 | grep block64
+RPG_LIB_PATH=$R/relpose-gnn_amd/lib/abl_block_1.so timeout 300 python tools/conv_bench.py --bf16 --block64 --nimg 512 --warm 10 2>&1 | grep block64
