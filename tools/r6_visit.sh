@@ -1,4 +1,5 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6aa; mkdir -p $OUT
-timeout 300 python tools/conv_bench.py --bf16 --block64 --nimg 512 --warm 10 2>&1 | grep block64
-RPG_LIB_PATH=$R/relpose-gnn_amd/lib/abl_block_1.so timeout 300 python tools/conv_bench.py --bf16 --block64 --nimg 512 --warm 10 2>&1 | grep block64
+# scratch driver of a GPU-box visit (round 6); edited per visit
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6ac; mkdir -p $OUT
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_hip_bf16.py -q -m gpu -x > $OUT/pytest.log 2>&1; echo "rc=$?" >> $OUT/pytest.log; tail -3 $OUT/pytest.log
