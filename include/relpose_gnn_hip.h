@@ -387,9 +387,11 @@ int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
                                      accumulator is folded into a second one and restarted every `value` of K (a multiple of 64; default 256; 0 = one
                                      sequential chain over all of K as in rounds 1-4).  Summation order only: cuts the rounding noise of the K = 2048..4096
                                      GNN Linears (reference: addmm in my_gnn_layer.py:236-239,304-311 through oneDNN's blocked sums) */
-#define RPG_TUNE_BF16_FUSE_BLOCK 27  /* bf16 encoder: 1 (default) = 64-channel identity BasicBlocks (ResNet34 layer 1) run as ONE kernel, conv1 + BN + ReLU
-                                     + conv2 + BN + identity + ReLU with the intermediate activation in LDS (rpg_basicblock64_bf16; bit-identical
-                                     to the two convolution launches) | 0 = two launches */
+#define RPG_TUNE_BF16_FUSE_BLOCK 27  /* bf16 encoder: 64-channel identity BasicBlocks (ResNet34 layer 1) run as ONE kernel, conv1 + BN + ReLU + conv2 +
+                                     BN + identity + ReLU with the intermediate activation in LDS (rpg_basicblock64_bf16; bit-identical to the two
+                                     convolution launches): 3 (default) = persistent form (one workgroup per CU walks the tiles, the next tile's
+                                     first loads under the current tile's last steps and epilogue; launches of more than one round of tiles) |
+                                     1 = one tile per workgroup (rounds 5-6a) | 0 = two launches */
 #define RPG_TUNE_BF16_TAIL 28        /* bf16 3x3 / stride-1 convolutions on more than one round of tiles: the rows beyond the last FULL round of workgroups
                                      go to a second launch of the patch kernel with smaller tiles instead of a mostly empty round of full-size ones
                                      (49 * 2^k pixels: 3.06 / 1.53 rounds at 512 images); same arithmetic per output, bit-identical.  Bit 0 (default

@@ -530,6 +530,43 @@ def test_fused_basicblock64_equals_two_convolutions(dev, shape):
     assert rel_err(got.float().cpu().permute(0, 3, 1, 2), yf) < 1e-2
 
 
+@pytest.mark.parametrize("shape", [(300, 64, 86), (96, 56, 56)])
+def test_fused_basicblock64_large_batches_and_persistent_form(dev, shape):
+    """Round 6: (i) regression -- the two-strip epilogue split the pixel index m into (virtual image, row, column) with a
+    multiply-high 'magic' division of m itself, exact only below 2^32 / (2880 - 2^32 mod 2880) = 1 636 801 pixels on 64 x 86 maps:
+    from real image 284 on, the LAST pixel of every second virtual image came out one image too high and its store was dropped (the
+    output kept whatever the allocation held).  The division is tile-relative now; 300 images of 64 x 86 must equal the same images
+    run 12 at a time, bit for bit, with the output buffers poisoned by the allocator's reuse pattern being irrelevant.
+    (ii) the PERSISTENT form of the kernel (RPG_TUNE_BF16_FUSE_BLOCK = 3: one workgroup per CU walks tiles b, b + 256, ..., the next
+    tile's first loads under the current tile's last nine steps) is bit-identical to one tile per workgroup."""
+    from relpose_gnn_amd import ops
+    n, h, w = shape
+    g = torch.Generator().manual_seed(77 + w)
+    x = torch.randn((n, h, w, 64), generator=g).bfloat16().to(dev)
+    w1 = (torch.randn((64, 3, 3, 64), generator=g) * (2.0 / 576) ** 0.5).bfloat16().to(dev)
+    w2 = (torch.randn((64, 3, 3, 64), generator=g) * (2.0 / 576) ** 0.5).bfloat16().to(dev)
+    s1, b1 = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.2).to(dev)
+    s2, b2 = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.2).to(dev)
+    try:
+        ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, 1)
+        parts = torch.cat([ops.basicblock64_bf16(x[i:i + 12].contiguous(), w1, s1, b1, w2, s2, b2) for i in range(0, n, 12)])
+        # fill the allocator's free blocks of this size with NaN patterns: a dropped store then shows
+        junk = torch.full_like(x, float("nan"))
+        del junk
+        one = ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2)
+        ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, 3)
+        junk = torch.full_like(x, float("nan"))
+        del junk
+        per = ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, 1)
+    assert bool(torch.isfinite(one.float()).all()) and bool(torch.isfinite(per.float()).all())
+    for name, got in (("one tile per workgroup", one), ("persistent", per)):
+        bad = (got != parts).nonzero()
+        assert bad.numel() == 0, (name, shape, int(bad.shape[0]), bad[:3].tolist(), bad[-3:].tolist())
+
+
 def test_fused_basicblock64_refuses_shapes_it_does_not_take(dev):
     """Maps wider than 120 pixels (two strips of 60 + 2 columns: the widest whose patch rows fit 64 slots) are outside the fused kernel's patch budget: the entry point says so
     (RPG_ERR_BAD_ARG) and the composite forward falls back to two launches (same results either way)."""

@@ -125,9 +125,27 @@ def main():
             return ops.conv2d_bn_act_nhwc_bf16(t, w2, s2, b2, x, stride=1, pad=1, relu=True)
         fl = 2 * 2.0 * n * h * w * 64 * 576
         same = torch.equal(two(), ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2))
+        def fused(mode):
+            ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, mode)
+            return ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2)
+        base = fused(1)
+        for mode in (1, 1, 3, 3, 3):
+            y = fused(mode)
+            d = (y != base)
+            if d.any():
+                idx = d.nonzero()
+                print(f"# mode {mode}: {int(d.sum())} elements differ from the first run; first {idx[0].tolist()} last {idx[-1].tolist()} "
+                      f"rows {sorted(set(idx[:, 1].tolist()))[:12]} cols {sorted(set(idx[:, 2].tolist()))[:12]}", flush=True)
+            else:
+                print(f"# mode {mode}: identical to the first run", flush=True)
+        same_ps = torch.equal(fused(3), base)
         for rep in range(3):
+            ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, 3)
+            mp, _ = timeit(lambda: ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2), args.reps)
+            ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, 1)
             m2, _ = timeit(two, args.reps)
             m1, _ = timeit(lambda: ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2), args.reps)
+            print(f"block64 images={n} map {h}x{w}  persistent {mp*1e3:7.1f} us (== one tile per workgroup: {same_ps})   ", end="")
             print(f"block64 images={n} map {h}x{w}  two launches {m2*1e3:7.1f} us ({fl/m2/1e9:6.1f} TF)   fused {m1*1e3:7.1f} us ({fl/m1/1e9:6.1f} TF)   "
                   f"ratio {m1/m2:.3f}   bit-identical {same}", flush=True)
         return
