@@ -1,8 +1,6 @@
 #!/bin/bash
 # scratch driver of a GPU-box visit (round 6); edited per visit
-R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6ag; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_hip_bf16.py -x -q -k "basicblock64 or block_fusion" 2>&1 | tail -5
-for t in "" "--tune 27=3" "" "--tune 27=3"; do
-timeout 600 python bench.py --graphs 64 --encoder-dtype bf16 --gnn-dtype bf16 --steps 10 --warmup 3 --no-other-configs --no-latency --cpu-baseline-seconds 0 $t 2>/dev/null | tail -1 | python -c "
-import sys, json; r = json.loads(sys.stdin.read()); print('$t', r['value'], r['ms_per_step'], r['roofline'].get('frac'))"
-done
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6aj; mkdir -p $OUT
+echo "== current library"; timeout 1500 python -m pytest tests/test_hip_history.py -q -x 2>&1 | tail -8 | cut -c1-400
+echo "== probe library with the old division (expected: failures on 256x341 bf16, 1 stream)"
+RPG_HIP_LIB=$R/relpose-gnn_amd/lib/librelpose_gnn_hip_probe.so timeout 900 python -m pytest tests/test_hip_history.py -q -k "previous_forward and bf16" 2>&1 | tail -12 | cut -c1-300
