@@ -79,6 +79,41 @@ def test_forward_does_not_depend_on_the_previous_forward(dev, h, w, graphs, dtyp
             assert bad.numel() == 0, (name, before, int(bad.shape[0]), bad[:4].tolist(), float((u - v).abs().max()))
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("h,w,graphs", [(224, 224, 448), (256, 341, 288)])
+def test_launches_beyond_2_gib_of_input_equal_the_same_graphs_in_pieces(dev, h, w, graphs, dtype):
+    """Maximum sizes: ONE launch of 448 graphs x 8 x 224x224 (3584 images, 2.16 GB of fp32 input: past 2^31 bytes; layer-1 launches of
+    11.2 M pixels) / 288 graphs x 8 x 256x341 (2304 images, 2.41 GB) on one stream -- 14 / 9 times the benched launch -- against the
+    same graphs 32 at a time (the benched launch).  Images are independent: the bf16 path must be BIT-identical (same kernels per
+    image from 21 graphs up, tools/probes/big_launch.py / profiles/r6_big_launch_probe.txt), the fp32 path within the north-star
+    1e-4 (its stream-K / Winograd splits depend on the launch size: summation order), and neither may depend on the workspaces' content."""
+    from relpose_gnn_amd.graph import fc_batch
+    m = _model(dev, h)
+    m.encoder_dtype = m.gnn_dtype = dtype
+    m.hip_streams = 1
+    x = torch.randn((graphs * NODES, 3 * h * w), generator=torch.Generator(device=dev).manual_seed(9), device=dev)
+    assert x.numel() * 4 > 2 ** 31
+    a0, r0, _ = m(fc_batch(x, NODES))
+    a0, r0 = a0.clone(), r0.clone()
+    for t in m._ws_pool._buf.values():
+        t.fill_(255)
+    a1, r1, _ = m(fc_batch(x, NODES))
+    assert bool(torch.isfinite(a0).all()) and bool(torch.isfinite(r0).all())
+    assert torch.equal(a0, a1) and torch.equal(r0, r1)
+    m._ws_pool.clear()
+    pa, pr = [], []
+    for g0 in range(0, graphs, 32):
+        a, r, _ = m(fc_batch(x[g0 * NODES:(g0 + 32) * NODES], NODES))
+        pa.append(a.clone())
+        pr.append(r.clone())
+    pa, pr = torch.cat(pa), torch.cat(pr)
+    if dtype == "bf16":
+        assert torch.equal(a0, pa) and torch.equal(r0, pr), (int((a0 != pa).sum()), int((r0 != pr).sum()))
+    else:
+        ea, er = float((a0 - pa).abs().max() / pa.abs().max()), float((r0 - pr).abs().max() / pr.abs().max())
+        assert ea < 1e-4 and er < 1e-4, (ea, er)
+
+
 @pytest.mark.parametrize("h,w,n", [(64, 86, 512), (56, 56, 512), (32, 43, 512), (28, 28, 512)])
 @pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (64, 128, 2), (128, 128, 1)])
 def test_bf16_convolutions_write_every_output_of_a_512_image_launch(dev, h, w, n, cin, cout, stride):
