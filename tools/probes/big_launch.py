@@ -12,7 +12,8 @@ import test_hip_history as T  # noqa: E402
 from relpose_gnn_amd.graph import fc_batch  # noqa: E402
 
 dev = torch.device("cuda:0")
-cases = [(224, 224, int(a)) for a in sys.argv[1:]] or [(224, 224, 128), (224, 224, 456), (256, 341, 112), (256, 341, 264)]
+cases = [(tuple(int(v) for v in a.split("x")) if "x" in a else (224, 224, int(a))) for a in sys.argv[1:]] or \
+    [(224, 224, 128), (224, 224, 456), (256, 341, 112), (256, 341, 264)]              # arguments: graphs (at 224x224) or HxWxgraphs
 for h, w, graphs in cases:
     ref = None
     for dtype in ("f32", "bf16"):
