@@ -74,6 +74,7 @@ def main():
         "fp32_1stream": lambda: run(fc, 1),
         "knn4_2streams": lambda: run(kn, 2),
         "bf16_all_2streams": lambda: run(fc, 2, "bf16", "bf16"),
+        "bf16_all_1stream": lambda: run(fc, 1, "bf16", "bf16"),      # (layer 1: 784 tiles on the persistent fused block)
         "eval_stream": lambda: (setattr(fc, "hip_streams", 2), setattr(fc, "encoder_dtype", "f32"), setattr(fc, "gnn_dtype", "f32"),
                                 torch.from_numpy(E.evaluate_stream(fc, host_graphs, dev, micro_batch=8).pred_poses))[-1],
         "ref_loop_lookahead": lambda: (setattr(fc, "hip_streams", 2), setattr(fc, "encoder_dtype", "f32"), setattr(fc, "gnn_dtype", "f32"),
