@@ -391,7 +391,8 @@ int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
                                      BN + identity + ReLU with the intermediate activation in LDS (rpg_basicblock64_bf16; bit-identical to the two
                                      convolution launches): 3 (default) = persistent form (one workgroup per CU walks the tiles, the next tile's
                                      first loads under the current tile's last steps and epilogue; launches of more than one round of tiles) |
-                                     1 = one tile per workgroup (rounds 5-6a) | 0 = two launches */
+                                     1 = one tile per workgroup (rounds 5-6a) | 5 = one tile per workgroup in the two-group schedule (waves 4-7 one
+                                     barrier behind waves 0-3: load / compute phases alternate on every SIMD; experiment, not faster) | 0 = two launches */
 #define RPG_TUNE_BF16_TAIL 28        /* bf16 3x3 / stride-1 convolutions on more than one round of tiles: the rows beyond the last FULL round of workgroups
                                      go to a second launch of the patch kernel with smaller tiles instead of a mostly empty round of full-size ones
                                      (49 * 2^k pixels: 3.06 / 1.53 rounds at 512 images); same arithmetic per output, bit-identical.  Bit 0 (default

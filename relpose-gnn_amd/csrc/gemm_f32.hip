@@ -792,7 +792,7 @@ extern "C" int rpg_set_tuning(int key, int value) {
         case RPG_TUNE_BF16_FAST: rpg::bf16_set_fast(value != 0); return RPG_OK;
         case RPG_TUNE_BF16_LEAN_EPI: rpg::bf16_set_lean_epi(value != 0); return RPG_OK;
         case RPG_TUNE_BF16_PERSIST: rpg::bf16_set_persist(value != 0); return RPG_OK;
-        case RPG_TUNE_BF16_FUSE_BLOCK: rpg::bf16_set_fuse_block((int)(value & 3)); return RPG_OK;
+        case RPG_TUNE_BF16_FUSE_BLOCK: rpg::bf16_set_fuse_block((int)(value & 7)); return RPG_OK;
         case RPG_TUNE_BF16_TAIL: if (value < 0 || value > 7) return RPG_ERR_BAD_ARG; rpg::bf16_set_tail(value); return RPG_OK;
         case RPG_TUNE_BF16_LINEAR_DMA: if (value != 0 && (value < 10 || value > 19)) return RPG_ERR_BAD_ARG; rpg::bf16_set_linear_dma(value); return RPG_OK;
         case RPG_TUNE_WINO2D:              // probe builds only (tools/probes/winograd2d.hip); the product accepts 0

@@ -558,11 +558,13 @@ def test_fused_basicblock64_large_batches_and_persistent_form(dev, shape):
         junk = torch.full_like(x, float("nan"))
         del junk
         per = ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2)
+        ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, 5)      # (iii) the two-group schedule (experiment, off by default): same MFMA order per accumulator
+        two_group = ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2)
         torch.cuda.synchronize()
     finally:
-        ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, 1)
+        ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, 3)
     assert bool(torch.isfinite(one.float()).all()) and bool(torch.isfinite(per.float()).all())
-    for name, got in (("one tile per workgroup", one), ("persistent", per)):
+    for name, got in (("one tile per workgroup", one), ("persistent", per), ("two-group schedule", two_group)):
         bad = (got != parts).nonzero()
         assert bad.numel() == 0, (name, shape, int(bad.shape[0]), bad[:3].tolist(), bad[-3:].tolist())
 
@@ -595,13 +597,14 @@ def test_bf16_encoder_with_and_without_block_fusion_is_bit_identical(dev):
     d = fc_batch(S.synth_images(48, 224, 224, seed=9), 8).to(dev)
     outs = []
     try:
-        for fuse in (1, 0):
+        for fuse in (3, 0, 1, 5):                         # persistent (default) | two launches | one tile per workgroup | two-group schedule
             ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, fuse)
             a, r, _ = m(d)
             outs.append((a.clone(), r.clone()))
     finally:
-        ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, 1)
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, 3)
+    for k in (1, 2, 3):
+        assert torch.equal(outs[0][0], outs[k][0]) and torch.equal(outs[0][1], outs[k][1]), k
     assert bool(torch.isfinite(outs[0][0]).all()) and float(outs[0][0].abs().max()) > 0
 
 

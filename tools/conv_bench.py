@@ -129,7 +129,7 @@ def main():
             ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, mode)
             return ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2)
         base = fused(1)
-        for mode in (1, 1, 3, 3, 3):
+        for mode in (1, 3, 3, 5, 5):
             y = fused(mode)
             d = (y != base)
             if d.any():
@@ -142,6 +142,9 @@ def main():
         for rep in range(3):
             ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, 3)
             mp, _ = timeit(lambda: ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2), args.reps)
+            ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, 5)
+            mpp, _ = timeit(lambda: ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2), args.reps)
+            print(f"block64 images={n} map {h}x{w}  two-group {mpp*1e3:7.1f} us   ", end="")
             ops.set_tuning(ops.TUNE_BF16_FUSE_BLOCK, 1)
             m2, _ = timeit(two, args.reps)
             m1, _ = timeit(lambda: ops.basicblock64_bf16(x, w1, s1, b1, w2, s2, b2), args.reps)
