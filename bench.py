@@ -248,6 +248,19 @@ def other_configs(model, args, dev):
                                      f"conv, {args.streams} streams, inputs resident in HBM",
                          "roofline": bf16_roofline(kt)}
         del x2, d2
+        # what the bf16 matrix pipe of THIS device sustains with nothing else drawing power (registers-only MFMA stream,
+        # rpg_probe_mfma_bf16): the data-sheet 2.5 PFLOP/s holds on zero operands only
+        try:
+            pipe = {k: round(ops.probe_mfma_bf16(k, iters=20000), 3) for k in ("zeros", "relu_like", "random")}
+            out["bf16_matrix_pipe_sustained_pflops"] = dict(pipe, what="chip-wide v_mfma_f32_32x32x16_bf16 on registers only (no LDS / L2 / "
+                                                            "HBM traffic), 2 x CUs workgroups x 8 waves x 20000 x 16 MFMAs, HIP events; the clock under the load "
+                                                            "depends on the operand data (power cap)")
+            for name in ("configs2_bf16_encoder", "configs2_bf16_all"):
+                tf = out[name]["roofline"]["achieved"]
+                out[name]["roofline"]["frac_of_sustained_pipe_relu_like"] = round(tf / 1e3 / pipe["relu_like"], 4)
+                out[name]["roofline"]["frac_of_sustained_pipe_random"] = round(tf / 1e3 / pipe["random"], 4)
+        except Exception as e:  # noqa: BLE001 -- a measurement aid: never fail the line over it
+            out["bf16_matrix_pipe_sustained_pflops"] = {"error": f"{type(e).__name__}: {e}"}
         model.hip_streams = args.streams
         # evaluation-shape streams: single-graph Data objects in pageable host memory, as a loader delivers them (test.py:193,211)
         h, w, mb = 256, 341, 64
@@ -723,6 +736,11 @@ def main():
                     cfg[short + "_gps"] = v.get("value")
                     cfg[short + "_ms"] = v.get("ms_per_step")
                     cfg[short + "_frac"] = (v.get("roofline") or {}).get("frac")
+                    if (v.get("roofline") or {}).get("frac_of_sustained_pipe_relu_like") is not None:
+                        cfg[short + "_frac_of_sustained_pipe"] = v["roofline"]["frac_of_sustained_pipe_relu_like"]
+            pipe = others.get("bf16_matrix_pipe_sustained_pflops")
+            if isinstance(pipe, dict) and "relu_like" in pipe:          # measured ceiling of the bf16 matrix pipe on this box, by operand data
+                cfg["bf16_pipe_zeros_pflops"], cfg["bf16_pipe_relu_like_pflops"], cfg["bf16_pipe_random_pflops"] = pipe["zeros"], pipe["relu_like"], pipe["random"]
             for short, key in (("c3_stream_fp32", "configs3_eval_stream_1gpu_host_fp32"), ("c4_stream_bf16", "configs4_eval_stream_1gpu_host_bf16")):
                 v = others.get(key)
                 if isinstance(v, dict):

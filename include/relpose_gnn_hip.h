@@ -309,6 +309,15 @@ int rpg_timing_read(double* ms, long long* launches, double* work);
  * the algorithmic direct-convolution FLOP).  executed may be NULL.                               */
 int rpg_timing_read_ex(double* ms, long long* launches, double* work, double* executed);
 
+/* Measurement aid for the bf16 roofline (no counterpart in the reference, which has no bf16 path and no
+ * benchmark harness -- /root/reference/python/niantic/testing/test.py:192-211 is the only caller): one launch of `workgroups` x 8
+ * waves, each issuing iters x 16 v_mfma_f32_32x32x16_bf16 on registers only (no LDS / L2 / HBM traffic), operands taken from
+ * `operands` (device, 65,536 x 16 bytes of bf16 values chosen by the caller: the sustained clock of the matrix pipe depends on
+ * them -- on MI355X 2.50 PFLOP/s on zeros, 1.8 on random data, 2.1 on ReLU-like data).  The caller times the launch on `stream`;
+ * FLOP = workgroups * 8 * iters * 16 * 32768.  `sink`: one float of device memory (never written in practice).
+ * RPG_ERR_BAD_ARG: null / misaligned operands, iters outside 1 .. 2^24, workgroups outside 1 .. 65536. */
+int rpg_probe_mfma_bf16(const void* operands, long iters, int workgroups, float* sink, void* stream);
+
 /* Tuning knobs of the f32 MFMA tile engine (benchmarking aid; defaults are the tuned choice).
  *   RPG_TUNE_TILE      -1 automatic (default) | 0: 128x128 | 1: 256x64 | 2: 64x64 | 3: 128x64 workgroup tile
  *   RPG_TUNE_BK        K-step: 0 automatic (default: 32 for the 128x128 tile, else 16) | 16 | 32

@@ -1912,3 +1912,40 @@ extern "C" int rpg_linear_bf16(const void* a, const void* weight, const float* b
     return rpg::launch_linear_bf16(a, weight, bias, residual, res_idx, residual2, res2_idx, ldr, out, m, k, n_out, relu,
                                    rpg::as_stream(stream));
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Measurement aid (no reference counterpart): what the bf16 matrix pipe of THIS device sustains chip-wide with
+// nothing else drawing power -- `iters` x 16 v_mfma_f32_32x32x16_bf16 per wave on 4 independent accumulators, operands from
+// `operands` (65,536 x 16 bytes of bf16: the caller chooses zeros / random / ReLU-like data; on MI355X the clock under this load is
+// 2.38 / 1.70 / 2.0 GHz respectively, tools/probes/mfma_power_probe_bf16.hip).  bench.py prices the bf16 convolutions against it next
+// to the data-sheet peak.  The caller times the launch (HIP events on `stream`); FLOP = workgroups * 8 * iters * 16 * 32768.
+__global__ __launch_bounds__(512) void mfma_pipe_probe_bf16_kernel(const uint4* __restrict__ src, float* sink, long iters) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    bf16x8 a[4], b[4];
+    for (int i = 0; i < 4; ++i) {
+        a[i] = __builtin_bit_cast(bf16x8, src[(t * 8 + i) & 65535]);
+        b[i] = __builtin_bit_cast(bf16x8, src[(t * 8 + 4 + i) & 65535]);
+    }
+    f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    for (long it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k], b[k], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k], b[(k + 1) & 3], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(k + 1) & 3], b[k], c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(k + 2) & 3], b[(k + 3) & 3], c3, 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+    if (s == 123.456f) sink[0] = s;
+}
+
+extern "C" int rpg_probe_mfma_bf16(const void* operands, long iters, int workgroups, float* sink, void* stream) {
+    if (!operands || !sink || iters <= 0 || iters > (1L << 24) || workgroups <= 0 || workgroups > 65536 || !rpg::aligned16(operands))
+        return RPG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(mfma_pipe_probe_bf16_kernel, dim3(workgroups), dim3(512), 0, rpg::as_stream(stream),
+                       reinterpret_cast<const uint4*>(operands), sink, iters);
+    RPG_CHECK_LAUNCH("probe_mfma_bf16");
+    return RPG_OK;
+}

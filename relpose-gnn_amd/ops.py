@@ -142,6 +142,34 @@ def basicblock64_bf16(x: torch.Tensor, w1_ohwi: torch.Tensor, scale1: torch.Tens
     return y
 
 
+def probe_mfma_bf16(data: str = "relu_like", iters: int = 20000, workgroups: int = 0, device=None) -> float:
+    """PFLOP/s that a chip-wide, registers-only stream of v_mfma_f32_32x32x16_bf16 sustains on this device with `data` operands
+    ("zeros" | "random" | "relu_like": half zeros, half uniform): the matrix pipe's own ceiling under the power cap
+    (rpg_probe_mfma_bf16; measurement aid of bench.py's bf16 roofline).  Timed with events on the current stream."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(17)
+    n = 65536 * 8
+    if data == "zeros":
+        v = torch.zeros(n, device=dev)
+    elif data == "random":
+        v = (torch.rand(n, generator=g, device=dev) - 0.5) * 2e-3
+    elif data == "relu_like":
+        v = torch.rand(n, generator=g, device=dev) * 2e-3 * (torch.rand(n, generator=g, device=dev) < 0.5)
+    else:
+        raise ValueError("data: zeros | random | relu_like")
+    src = v.bfloat16().contiguous()
+    sink = torch.zeros(1, device=dev)
+    wgs = workgroups or 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+    lib = L.lib()
+    L.check(lib.rpg_probe_mfma_bf16(_p(src), max(1, iters // 10), wgs, _p(sink), _stream()), "probe_mfma_bf16")      # warm (clock ramp)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(lib.rpg_probe_mfma_bf16(_p(src), iters, wgs, _p(sink), _stream()), "probe_mfma_bf16")
+    e1.record()
+    e1.synchronize()
+    return wgs * 8 * iters * 16 * 32768.0 / (e0.elapsed_time(e1) * 1e-3) / 1e15
+
+
 def f32_to_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None, col_off: int = 0) -> torch.Tensor:
     """bf16 image of the fp32 matrix x [rows][cols] (written at column col_off of `out` when given)."""
     x = _req(x, "x")

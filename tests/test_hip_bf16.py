@@ -687,3 +687,17 @@ def test_patch_kernel_tail_retiling_is_bit_identical(dev, n, h, w, c, res):
         if res:
             ref = ref + r[i:i + 1].float().permute(0, 3, 1, 2).cpu()
         assert rel_err(outs[3][i:i + 1].float().cpu().permute(0, 3, 1, 2), F.relu(ref)) < 1e-2
+
+
+def test_matrix_pipe_probe_runs_and_orders_the_operand_data(dev):
+    """rpg_probe_mfma_bf16 (measurement aid of bench.py's bf16 roofline): a registers-only MFMA stream; on MI355X the sustained
+    rate depends on the operand data through the power cap -- zeros fastest (2.5 PFLOP/s), ReLU-like (2.1), random (1.8).  The test
+    pins what is robust: it runs, the rate is in the physical range, zeros are not slower than random data, bad arguments are refused."""
+    from relpose_gnn_amd import _lib, ops
+    z = ops.probe_mfma_bf16("zeros", iters=4000)
+    r = ops.probe_mfma_bf16("random", iters=4000)
+    assert 0.3 < r < 2.7 and 0.3 < z < 2.7, (z, r)
+    assert z > 0.95 * r, (z, r)
+    sink = torch.zeros(1, device=dev)
+    assert _lib.lib().rpg_probe_mfma_bf16(None, 10, 256, sink.data_ptr(), None) == _lib.RPG_ERR_BAD_ARG
+    assert _lib.lib().rpg_probe_mfma_bf16(sink.data_ptr(), 0, 256, sink.data_ptr(), None) == _lib.RPG_ERR_BAD_ARG
