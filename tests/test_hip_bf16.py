@@ -697,7 +697,7 @@ def test_matrix_pipe_probe_runs_and_orders_the_operand_data(dev):
     z = ops.probe_mfma_bf16("zeros", iters=4000)
     r = ops.probe_mfma_bf16("random", iters=4000)
     assert 0.3 < r < 2.7 and 0.3 < z < 2.7, (z, r)
-    assert z > 0.95 * r, (z, r)
+    assert z > 0.85 * r, (z, r)
     sink = torch.zeros(1, device=dev)
     assert _lib.lib().rpg_probe_mfma_bf16(None, 10, 256, sink.data_ptr(), None) == _lib.RPG_ERR_BAD_ARG
     assert _lib.lib().rpg_probe_mfma_bf16(sink.data_ptr(), 0, 256, sink.data_ptr(), None) == _lib.RPG_ERR_BAD_ARG
