@@ -1,6 +1,5 @@
 #!/bin/bash
-# Scratch driver of a round-6 GPU-box visit (gpurun -- 'bash tools/r6_visit.sh'); edited per visit.  Last content: the final check.
-R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6_final; mkdir -p $OUT
-timeout 3000 python -m pytest tests -q -x -m gpu 2>&1 | tail -4
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc $?"; tail -1 $OUT/bench.json | cut -c1-400
+# scratch driver of a GPU-box visit (round 6); edited per visit
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6bc; mkdir -p $OUT
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mlpb tools/probes/mfma_lds_power_probe_bf16.hip 2>/dev/null
+timeout 600 /tmp/mlpb 2>&1 | tee $OUT/mfma_lds_power_bf16.txt
