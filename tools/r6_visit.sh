@@ -1,5 +1,4 @@
 #!/bin/bash
 # scratch driver of a GPU-box visit (round 6); edited per visit
-R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6bc; mkdir -p $OUT
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mlpb tools/probes/mfma_lds_power_probe_bf16.hip 2>/dev/null
-timeout 600 /tmp/mlpb 2>&1 | tee $OUT/mfma_lds_power_bf16.txt
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; OUT=gpurun_out/r6bd; mkdir -p $OUT
+timeout 500 python tools/soak.py --seconds 300 > $OUT/soak.json 2> $OUT/soak.err; echo "soak rc $?"; cat $OUT/soak.json; tail -3 $OUT/soak.err | grep -v amdgpu

@@ -40,6 +40,19 @@ def main():
         return m.to(dev).eval()
 
     fc, kn = build(-1), build(4)
+    # the 256 x 341 evaluation shape, bf16, one stream, 40 graphs = 320 images per launch: the two-strip persistent fused block on
+    # 64 x 86 maps past the 1.6-M-pixel mark where round 6 found (and fixed) a dropped store
+    H2, W2 = 256, 341
+    ev = PoseNetX_R2(resnet34(), droprate=0.0, pretrained=False, feat_dim=D, edge_feat_dim=D, node_dim=D, input_img_height=H2,
+                     use_gnn=True, knn=-1, use_AP=True, gnn_recursion=2)
+    ev.load_state_dict(sd)
+    ev = ev.to(dev).eval()
+    ev.hip_streams, ev.encoder_dtype, ev.gnn_dtype = 1, "bf16", "bf16"
+    data_ev = fc_batch(torch.randn((8 * 40, 3 * H2 * W2), generator=torch.Generator(device=dev).manual_seed(11), device=dev), 8)
+
+    def run_ev():
+        a, r, ei = ev(data_ev)
+        return torch.cat([a.flatten(), r.flatten()])
     x = torch.randn((8 * args.graphs, 3 * H * W), generator=torch.Generator(device=dev).manual_seed(9), device=dev)
     data = fc_batch(x, 8)
     gen = torch.Generator().manual_seed(10)
@@ -75,6 +88,7 @@ def main():
         "knn4_2streams": lambda: run(kn, 2),
         "bf16_all_2streams": lambda: run(fc, 2, "bf16", "bf16"),
         "bf16_all_1stream": lambda: run(fc, 1, "bf16", "bf16"),      # (layer 1: 784 tiles on the persistent fused block)
+        "bf16_eval_256x341_40graphs_1stream": run_ev,
         "eval_stream": lambda: (setattr(fc, "hip_streams", 2), setattr(fc, "encoder_dtype", "f32"), setattr(fc, "gnn_dtype", "f32"),
                                 torch.from_numpy(E.evaluate_stream(fc, host_graphs, dev, micro_batch=8).pred_poses))[-1],
         "ref_loop_lookahead": lambda: (setattr(fc, "hip_streams", 2), setattr(fc, "encoder_dtype", "f32"), setattr(fc, "gnn_dtype", "f32"),
