@@ -274,7 +274,9 @@ def other_configs(model, args, dev):
         for name, dt_name, n in (("configs3_eval_stream_1gpu_host_fp32", "f32", 2000), ("configs4_eval_stream_1gpu_host_bf16", "bf16", 4000)):
             model.encoder_dtype = model.gnn_dtype = dt_name
             legs = {}
-            for leg, src, bfin in (("pinned", pinned_pool, None), ("pageable", pool, None)) + ((("pinned_host_rounded", pinned_pool, True),) if dt_name == "bf16" else ()):
+            # (bf16 leg pinned_direct: bf16_input=False = the loader's pinned fp32 tensors sent as they are, rounded on the device --
+            # what a rank of an 8-rank host does with its 2 staging threads; `pinned` = the automatic choice of THIS process)
+            for leg, src, bfin in (("pinned", pinned_pool, None), ("pageable", pool, None)) + ((("pinned_direct", pinned_pool, False),) if dt_name == "bf16" else ()):
                 graphs = [Data(x=src[i % len(src)][0], edge_index=ei8, y=src[i % len(src)][1]) for i in range(n)]
                 E.evaluate_stream(model, graphs[:2 * mb], dev, micro_batch=mb, bf16_input=bfin)   # warm-up: packing, workspaces, staging buffers
                 torch.cuda.synchronize()
@@ -296,9 +298,10 @@ def other_configs(model, args, dev):
                                      f"images in PINNED host memory (the reference's DataLoader(pin_memory=True), test.py:193) -> evaluate_stream "
                                      f"(micro-batch {mb}, H2D on a copy stream"
                                      + (": fp32 sources go straight from the loader's pinned tensors, no staging copy" if dt_name == "f32" else
-                                        ": pinned fp32 sources go straight from the loader's tensors as they are -- no rounding pass, no staging "
-                                        "copy; leg pinned_host_rounded forces the staging threads' bf16 rounding (half the H2D bytes), which is what "
-                                        "pageable sources get")
+                                        ": with >= 8 staging threads (this process) the images are rounded to bf16 by the staging threads while the "
+                                        "previous micro-batch is post-processed (half the H2D bytes: the link carries 6.1 k graphs/s of fp32 images, "
+                                        "the forward does 8 k); leg pinned_direct sends the loader's pinned fp32 tensors as they are (no host pass: "
+                                        "what a rank with 2-4 staging threads does)")
                                      + ", D2H + test.py:213-251 post-processing per graph included); legs.pageable = the same stream out of "
                                      "pageable memory; the 4- / 8-GPU sharding is tools/eval_stream.py under torch.distributed.run"}
         del pinned_pool

@@ -369,6 +369,11 @@ int rpg_probe_mfma_bf16(const void* operands, long iters, int workgroups, float*
 /* HOST: fp32 -> bf16 (round to nearest even, NaN -> quiet NaN: what the device's conversion and torch's .bfloat16() do) of a
  * contiguous host array; thread-safe, called by evaluate_stream's staging threads for the bf16 encoder's node images. */
 int rpg_host_f32_to_bf16(const float* src, void* dst_bf16, size_t count);
+/* HOST: the same with the instruction set named (round 6: the conversion runs on 8 / 16 lanes where the CPU has AVX2 / AVX-512F,
+ * chosen once at run time by rpg_host_f32_to_bf16; every variant is the same integer arithmetic, bit-identical).  isa: 0 = what
+ * rpg_host_f32_to_bf16 uses on this CPU | 1 = scalar | 2 = AVX2 | 3 = AVX-512F.  RPG_ERR_BAD_ARG for an unknown index or an
+ * instruction set this CPU lacks (tests compare every available variant with the scalar one). */
+int rpg_host_f32_to_bf16_isa(const float* src, void* dst_bf16, size_t count, int isa);
 
 #define RPG_TUNE_SK_MIN_ITS 19    /* least K steps a stream-K workgroup of the fp32 GEMM engine gets (default 8) */
 #define RPG_TUNE_INKERNEL_FIXUP 20  /* experiment of round 4, OFF by default (measured slower on MI355X): the partial tiles of a

@@ -27,7 +27,7 @@ SYMBOLS = (
     "rpg_resnet_forward_bf16", "rpg_gnn_forward_bf16", "rpg_f32_to_bf16", "rpg_linear_bf16",
     "rpg_release_scratch", "rpg_timing_read_ex", "rpg_stem_conv7x7s2_bn_relu_maxpool_f32", "rpg_stem_pair_table",
     "rpg_attention_aggregate_f32", "rpg_stem_conv7x7s2_bn_relu_maxpool_bf16", "rpg_stem_conv7x7s2_bn_relu_maxpool_bf16_xbf16",
-    "rpg_resnet_forward_bf16_xbf16", "rpg_host_f32_to_bf16", "rpg_basicblock64_bf16", "rpg_linear_gather_ex_f32", "rpg_probe_mfma_bf16",
+    "rpg_resnet_forward_bf16_xbf16", "rpg_host_f32_to_bf16", "rpg_basicblock64_bf16", "rpg_linear_gather_ex_f32", "rpg_probe_mfma_bf16", "rpg_host_f32_to_bf16_isa",
 )
 
 
@@ -95,6 +95,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.rpg_stem_conv7x7s2_bn_relu_maxpool_bf16_xbf16.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]
     lib.rpg_resnet_forward_bf16_xbf16.argtypes = lib.rpg_resnet_forward_bf16.argtypes
     lib.rpg_host_f32_to_bf16.argtypes = [_vp, _vp, _sz]
+    lib.rpg_host_f32_to_bf16_isa.argtypes = [_vp, _vp, _sz, _i]
     lib.rpg_probe_mfma_bf16.argtypes = [_vp, C.c_long, _i, _vp, _vp]
     for name in SYMBOLS:
         getattr(lib, name)          # AttributeError here = the library does not export a declared symbol

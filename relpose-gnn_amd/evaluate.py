@@ -133,6 +133,12 @@ class _InputPipeline:
 
     def stage(self, k: int, chunk) -> torch.Tensor:
         """Collate the chunk's node images into pinned buffer k and enqueue the H2D copy; returns the device view."""
+        return self.stage_end(self.stage_begin(k, chunk))
+
+    def stage_begin(self, k: int, chunk):
+        """First half of ``stage``: hand the chunk's pageable -> pinned copies (or bf16 roundings) to the staging threads and
+        return at once; ``stage_end`` waits for them and enqueues the H2D copy.  Between the two the caller may do other host
+        work (round 6: ``evaluate_stream`` post-processes the previous micro-batch there -- the copies release the GIL)."""
         if self.n_sent[k]:
             self.sent[k].synchronize()                 # the previous copy out of pinned buffer k has left the host
         host, dev, off = self.host[k], self.dev[k], 0
@@ -167,10 +173,18 @@ class _InputPipeline:
             w = min(len(jobs), self.workers)
             if w <= 1:
                 copy_some(jobs)
+                futs = []
             else:
                 futs = [self.pool.submit(copy_some, jobs[i::w]) for i in range(w)]
-                for f in futs:
-                    f.result()
+        else:
+            futs = []
+        return k, off, direct, futs
+
+    def stage_end(self, handle) -> torch.Tensor:
+        k, off, direct, futs = handle
+        host, dev = self.host[k], self.dev[k]
+        for f in futs:
+            f.result()
         with torch.cuda.stream(self.copy_stream):
             if self.n_sent[k]:
                 self.copy_stream.wait_event(self.used[k])      # the forward that read device buffer k has finished
@@ -221,17 +235,20 @@ class _MicroBatchRunner:
                  pinned_direct: bool = True):
         self.model, self.device, self.micro_batch = model, device, int(micro_batch)
         self.h2d_dtype, self.local_world, self.want_abs = h2d_dtype, local_world, want_abs
-        # pinned_direct (the default when the caller did not force a staging dtype): a micro-batch whose fp32 images ALL sit in
-        # pinned host memory -- what the reference's DataLoader(pin_memory=True) delivers, testing/test.py:193 -- goes to the
-        # device as it is, straight from the loader's tensors, even where the model would take host-rounded bf16: the rounding
-        # pass is the only per-byte host work of the stream (16 staging threads per rank, a budget the ranks of a host share),
-        # and a Gen5 x16 link moves the fp32 images faster than those threads round them (measured round 6, one GPU: 6.0 k
-        # graphs/s against 5.5 k; at 8 ranks the staging threads' 200 GB/s aggregate ceiling no longer applies)
-        self.pinned_direct = bool(pinned_direct)
+        # pinned_direct (when the caller did not force a staging dtype): a micro-batch whose fp32 images ALL sit in pinned host
+        # memory -- what the reference's DataLoader(pin_memory=True) delivers, testing/test.py:193 -- goes to the device as it is,
+        # straight from the loader's tensors.  For the fp32 model always (there is nothing to do on the host).  For a model that
+        # takes host-rounded bf16 images it depends on what the rank can spend: the rounding pass halves the H2D bytes, and a Gen5
+        # x16 link carries 51 GB/s = 6.1 k graphs/s of fp32 256 x 341 images where the bf16 forward does 8 k; with the staging
+        # overlapped with the post-processing (round 6) 16 rounding threads deliver 7.8 k graphs/s, so a rank with >= 8 staging
+        # threads (one or two ranks per host: staging_workers) rounds, and a rank with its 2-4 threads of an 8-rank host (2 threads
+        # round ~27 ms per micro-batch) sends the loader's tensors as they are.
+        self.pinned_direct = bool(pinned_direct) and not (h2d_dtype != torch.float32 and staging_workers(False, local_world) >= 8)
         self.on_gpu = torch.device(device).type == "cuda"
         self.pipes = {}                    # staging dtype -> _InputPipeline (at most two: the configured dtype, fp32 for pinned sources)
         self.n_batches = 0
         self.h2d_bytes = 0
+        self._prefetched = None            # (chunk, pipe, stage_begin handle) of the chunk the next launch() is expected to get
 
     @property
     def pipe(self) -> Optional[_InputPipeline]:
@@ -242,6 +259,29 @@ class _MicroBatchRunner:
         return {"staged_bytes": sum(p.staged_bytes for p in ps), "direct_bytes": sum(p.direct_bytes for p in ps),
                 "staging_workers": max((p.workers for p in ps), default=0)}
 
+    def _begin_staging(self, k: int, chunk):
+        """Pick (or build) the chunk's pipeline and start its staging copies: -> (pipe, handle of _InputPipeline.stage_begin)."""
+        device = self.device
+        rows, width = sum(g.x.shape[0] for g in chunk), int(chunk[0].x.shape[1])
+        dtype = self.h2d_dtype
+        if self.pinned_direct and dtype != torch.float32 and all(g.x.dtype == torch.float32 and g.x.is_pinned() for g in chunk):
+            dtype = torch.float32                               # the loader's own pinned fp32 tensors: no rounding pass, no staging copy
+        pipe = self.pipes.get(dtype)
+        if pipe is None or not pipe.fits(rows, width, dtype):
+            if pipe is not None:
+                torch.cuda.synchronize(device)                  # a larger buffer pair replaces one that is in flight
+            cap = max(rows, max(g.x.shape[0] for g in chunk) * self.micro_batch)
+            pipe = self.pipes[dtype] = _InputPipeline(torch.device(device), cap, width, dtype, self.local_world)
+        return pipe, pipe.stage_begin(k, chunk)
+
+    def prefetch(self, chunk: Sequence[Data]) -> None:
+        """Start staging the chunk the NEXT ``launch`` call will get (its pageable -> pinned copies / bf16 roundings run on the
+        staging threads while the caller does other host work); ``launch`` picks the result up if it is handed the same chunk."""
+        if self._prefetched is not None or not chunk or not self.on_gpu or any(g.x.is_cuda for g in chunk):
+            return
+        pipe, handle = self._begin_staging(self.n_batches & 1, chunk)
+        self._prefetched = (chunk, pipe, handle)
+
     def launch(self, chunk: Sequence[Data]):
         """-> (chunk, host_rel, host_ei | None, ev | None, host_abs | None, batch): batch = the collated micro-batch the forward
         read (batch.x: the chunk's node images, rows in chunk order; batch.edge_index: batch node ids)."""
@@ -249,18 +289,13 @@ class _MicroBatchRunner:
         k = self.n_batches & 1
         self.n_batches += 1
         staged = self.on_gpu and not any(g.x.is_cuda for g in chunk)
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and (not staged or len(pre[0]) != len(chunk) or any(a is not b for a, b in zip(pre[0], chunk))):
+            pre[1].stage_end(pre[2])                                # a prefetch for another chunk: complete it (keeps the buffers' events in order), then drop it
+            pre = None
         if staged:
-            rows, width = sum(g.x.shape[0] for g in chunk), int(chunk[0].x.shape[1])
-            dtype = self.h2d_dtype
-            if self.pinned_direct and dtype != torch.float32 and all(g.x.dtype == torch.float32 and g.x.is_pinned() for g in chunk):
-                dtype = torch.float32                               # the loader's own pinned fp32 tensors: no rounding pass, no staging copy
-            pipe = self.pipes.get(dtype)
-            if pipe is None or not pipe.fits(rows, width, dtype):
-                if pipe is not None:
-                    torch.cuda.synchronize(device)                  # a larger buffer pair replaces one that is in flight
-                cap = max(rows, max(g.x.shape[0] for g in chunk) * self.micro_batch)
-                pipe = self.pipes[dtype] = _InputPipeline(torch.device(device), cap, width, dtype, self.local_world)
-            x_dev = pipe.stage(k, chunk)
+            pipe, handle = (pre[1], pre[2]) if pre is not None else self._begin_staging(k, chunk)
+            x_dev = pipe.stage_end(handle)
             self.h2d_bytes += x_dev.numel() * x_dev.element_size()
             batch = _collate_on_device(chunk, x_dev, device)
             pipe.acquire(k)
@@ -346,9 +381,6 @@ def _evaluate_stream(model, graphs, device, micro_batch, pose_m, pose_s, ref_nod
     h2d_dtype = torch.bfloat16 if (bf16_input if bf16_input is not None else getattr(model, "accepts_bf16_input", False)) else torch.float32
     runner = _MicroBatchRunner(model, device, micro_batch, h2d_dtype, local_world, pinned_direct=bf16_input is None)
 
-    def launch(b0):
-        return runner.launch([graphs[i] for i in range(b0, min(hi, b0 + micro_batch))])
-
     def finish(item):
         chunk, host, host_ei, ev = item[:4]
         if ev is not None:
@@ -376,9 +408,22 @@ def _evaluate_stream(model, graphs, device, micro_batch, pose_m, pose_s, ref_nod
 
     import time
     t_local = time.perf_counter()
+    # Round 6: while the main thread post-processes micro-batch i - 1 (test.py:213-251 restated: ~3 ms of small numpy calls per
+    # 64 graphs), the staging threads already copy / round micro-batch i + 1 into its pinned buffer (they release the GIL); its
+    # H2D copy is then enqueued first thing in the next iteration, under the forward of micro-batch i.  Before, staging, launch and
+    # post-processing took turns on the main thread and the bf16 stream at 256 x 341 was bound by that loop (9.5 ms per micro-batch
+    # against 7.8 ms of GPU work).  Same launches, same order, same numbers.
+    def chunk_at(b0):
+        return [graphs[i] for i in range(b0, min(hi, b0 + micro_batch))]
+
     pending = None
+    nxt = chunk_at(lo) if lo < hi else []
     for b0 in range(lo, hi, micro_batch):
-        item = launch(b0)
+        chunk = nxt
+        item = runner.launch(chunk)
+        nxt = chunk_at(b0 + micro_batch) if b0 + micro_batch < hi else []
+        if nxt:
+            runner.prefetch(nxt)
         if pending is not None:
             finish(pending)
         pending = item

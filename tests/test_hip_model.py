@@ -429,15 +429,28 @@ def test_bf16_encoder_takes_host_rounded_bf16_images(dev):
         per_elt = {"bf16_staging": 2, "fp32_staging": 4, "resident": 0}[kind]
         assert st["h2d_bytes"] == per_elt * sum(sizes) * 3 * 32 * 40, (kind, st)
     assert np.array_equal(res["bf16_staging"], res["fp32_staging"]) and np.array_equal(res["resident"], res["fp32_staging"])
-    # round 6: fp32 images in PINNED memory (the reference's DataLoader(pin_memory=True), test.py:193) go to the device as they are
-    # -- no rounding pass, no staging copy -- unless the caller forces the rounding (bf16_input=True); a stream that mixes pinned and
-    # pageable micro-batches uses both pipelines; the poses never change
+    # round 6: fp32 images in PINNED memory (the reference's DataLoader(pin_memory=True), test.py:193).  A rank with few staging
+    # threads (the 2-4 of an 8-rank host; here RPG_STAGE_WORKERS = 2) sends them as they are -- no rounding pass, no staging copy --,
+    # a rank with >= 8 rounds them on the host (half the H2D bytes: the link, not the forward, bounds the bf16 stream otherwise);
+    # bf16_input=True forces the rounding; a stream that mixes pinned and pageable micro-batches uses both pipelines; the poses
+    # never change
     pinned = [Data(x=g.x.clone().pin_memory(), edge_index=g.edge_index, y=g.y) for g in graphs]
     total = sum(sizes) * 3 * 32 * 40
-    for kind, gs, flag, want in (("pinned_auto", pinned, None, (4 * total, 0, 4 * total)), ("pinned_forced_bf16", pinned, True, (2 * total, 2 * total, 0)),
-                                 ("pinned_then_pageable", pinned[:3] + graphs[3:], None, None)):
+    import os
+    for kind, gs, flag, want, workers in (("pinned_auto_few_threads", pinned, None, (4 * total, 0, 4 * total), "2"),
+                                          ("pinned_auto_many_threads", pinned, None, (2 * total, 2 * total, 0), "16"),
+                                          ("pinned_forced_bf16", pinned, True, (2 * total, 2 * total, 0), "2"),
+                                          ("pinned_then_pageable", pinned[:3] + graphs[3:], None, None, "2")):
         st = {}
-        got = E.evaluate_stream(m, gs, dev, micro_batch=3, stats=st, bf16_input=flag).pred_poses
+        old_env = os.environ.get("RPG_STAGE_WORKERS")
+        os.environ["RPG_STAGE_WORKERS"] = workers
+        try:
+            got = E.evaluate_stream(m, gs, dev, micro_batch=3, stats=st, bf16_input=flag).pred_poses
+        finally:
+            if old_env is None:
+                del os.environ["RPG_STAGE_WORKERS"]
+            else:
+                os.environ["RPG_STAGE_WORKERS"] = old_env
         assert np.array_equal(got, res["fp32_staging"]), kind
         if want is not None:
             assert (st["h2d_bytes"], st["staged_bytes"], st["direct_bytes"]) == want, (kind, st)

@@ -235,3 +235,21 @@ def test_host_f32_to_bf16_is_round_to_nearest_even():
         assert torch.equal(out.view(torch.int16)[~nan], ref.view(torch.int16)[~nan])
         assert torch.isnan(out[nan]).all() and nan.sum() == torch.isnan(t).sum()
     assert lib.rpg_host_f32_to_bf16(None, None, 0) == _lib.RPG_OK and lib.rpg_host_f32_to_bf16(None, None, 4) == _lib.RPG_ERR_BAD_ARG
+    # round 6: the vector variants (AVX2 / AVX-512F where this CPU has them) are the scalar loop's arithmetic on 8 / 16 lanes: bit for bit
+    # the same, at every length (scalar head up to the 32-byte store alignment, vector body, scalar tail) and destination alignment
+    both = torch.cat([x, bits])
+    want = torch.empty(both.shape, dtype=torch.bfloat16)
+    assert lib.rpg_host_f32_to_bf16_isa(both.data_ptr(), want.data_ptr(), both.numel(), 1) == _lib.RPG_OK
+    ran = 0
+    for isa in (0, 2, 3):
+        for n, off in ((both.numel(), 0), (1000, 3), (31, 1), (16, 0), (15, 5), (1, 0), (0, 0)):
+            out = torch.full((n + off + 16,), 7.0, dtype=torch.bfloat16)
+            rc = lib.rpg_host_f32_to_bf16_isa(both.data_ptr(), out.data_ptr() + 2 * off, n, isa)
+            if rc == _lib.RPG_ERR_BAD_ARG and isa in (2, 3):
+                break                                                              # this CPU lacks the instruction set
+            assert rc == _lib.RPG_OK
+            assert torch.equal(out.view(torch.int16)[off:off + n], want.view(torch.int16)[:n]), (isa, n, off)
+            assert bool((out[:off] == 7.0).all()) and bool((out[off + n:] == 7.0).all()), (isa, n, off)      # nothing written outside
+            ran += 1
+    assert ran >= 7
+    assert lib.rpg_host_f32_to_bf16_isa(both.data_ptr(), want.data_ptr(), 4, 9) == _lib.RPG_ERR_BAD_ARG
