@@ -29,7 +29,8 @@ for isa in (1, 2, 3):
             t0 = time.perf_counter()
             rc = list(pool.map(work, range(threads)))
             dt = time.perf_counter() - t0
-        print(f"rpg_host_f32_to_bf16 isa {isa} ({'scalar', 'AVX2', 'AVX-512F'}[isa - 1]) threads {threads:2d}: rc {rc[0]}  {threads * n * 4 / dt / 1e9:7.1f} GB/s of fp32", flush=True)
+        name = ("scalar", "AVX2", "AVX-512F")[isa - 1]
+        print(f"rpg_host_f32_to_bf16 isa {isa} ({name}) threads {threads:2d}: rc {rc[0]}  {threads * n * 4 / dt / 1e9:7.1f} GB/s of fp32", flush=True)
 del src, dst
 
 dev = torch.device("cuda:0")
